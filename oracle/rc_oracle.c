@@ -1,0 +1,281 @@
+/*
+ * rc_oracle.c -- CPU restatement of the reference's cube arithmetic and env loops.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under rubiks-cube-solver_amd/ may include, link or
+ * call this file.  Its users are tests/, __graft_entry__.smoke() and the `cpu_baseline`
+ * leg of bench.py, and only as the checker / the timed CPU comparator.
+ *
+ * Parity status
+ *   3x3x3: PINNED.  oracle/oracle_np.py feeds this file the reference's own tables from
+ *          tests/golden/tables_333.npz (captured by importing the reference, see
+ *          tests/golden/make_golden.py) and tests/test_oracle.py replays every golden
+ *          vector (G2..G7) through it.
+ *   2x2x2: PARITY UNPINNED.  assets/py222.py is imported by the reference
+ *          (gym-cube/gym_cube/envs/cube_env.py:8) but is not in its tree and no version
+ *          is pinned; the oracle restates the published algorithm of the public
+ *          MeepMoop/py222 (tables built in oracle_np.py).
+ *
+ * Every function cites the reference lines it follows (paths relative to
+ * /root/reference/gym-cube/gym_cube/envs unless noted).  Data layout here is the
+ * reference's: one cube = S consecutive values (array of structures), one cube at a time.
+ *
+ * The ADI generator's random stream (orc_walk_rng_*) is NOT from the reference (which
+ * uses numpy's global legacy RNG, cube_env.py:189); it restates the build's own
+ * xoroshiro128+/splitmix64 specification (DESIGN.md "RNG") so the HIP kernel's action
+ * draws can be checked bit for bit.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_MAX_S 54
+#define ORC_MAX_A 12
+#define ORC_MAX_SLOTS 20
+
+typedef struct {
+    int cube_size, S, A, face;      /* face = stickers per face */
+    int n_corner, n_edge;           /* slots */
+    uint8_t perm[ORC_MAX_A][ORC_MAX_S];       /* assets/py333.py:46-138  moveDefs */
+    uint8_t corner_defs[8][3];                /* py333.py:140-149 */
+    uint8_t edge_defs[12][2];                 /* py333.py:151-164 */
+    int corner_rows, edge_rows;
+    uint8_t corner_lut[128][2];               /* py333.py:171-180 (zeros default) */
+    uint8_t edge_lut[128][2];                 /* py333.py:182-198 */
+} orc_tables;
+
+static orc_tables T[4]; /* indexed by cube_size (2,3) */
+
+int orc_set_tables(int cube_size, int S, int A, const uint8_t *perm,
+                   int n_corner, const uint8_t *corner_defs, int n_edge, const uint8_t *edge_defs,
+                   int corner_rows, const uint8_t *corner_lut, int edge_rows, const uint8_t *edge_lut)
+{
+    if (cube_size < 2 || cube_size > 3 || S > ORC_MAX_S || A > ORC_MAX_A) return -1;
+    if (n_corner > 8 || n_edge > 12 || corner_rows > 128 || edge_rows > 128) return -1;
+    orc_tables *t = &T[cube_size];
+    memset(t, 0, sizeof *t);
+    t->cube_size = cube_size; t->S = S; t->A = A; t->face = cube_size * cube_size;
+    t->n_corner = n_corner; t->n_edge = n_edge;
+    for (int a = 0; a < A; a++) memcpy(t->perm[a], perm + (size_t)a * S, S);
+    memcpy(t->corner_defs, corner_defs, (size_t)n_corner * 3);
+    if (n_edge) memcpy(t->edge_defs, edge_defs, (size_t)n_edge * 2);
+    t->corner_rows = corner_rows; t->edge_rows = edge_rows;
+    memcpy(t->corner_lut, corner_lut, (size_t)corner_rows * 2);
+    if (edge_rows) memcpy(t->edge_lut, edge_lut, (size_t)edge_rows * 2);
+    return 0;
+}
+
+/* initState_3 (py333.py:211-218): sticker i has colour i / 9 (i / 4 for py222's initState). */
+void orc_init_state(int cube_size, uint8_t *s)
+{
+    const orc_tables *t = &T[cube_size];
+    for (int i = 0; i < t->S; i++) s[i] = (uint8_t)(i / t->face);
+}
+
+/* doMove_3 (py333.py:220-222): new = s[moveDefs[move]], a fresh array. */
+void orc_do_move(int cube_size, const uint8_t *s, int move, uint8_t *out)
+{
+    const orc_tables *t = &T[cube_size];
+    uint8_t tmp[ORC_MAX_S];
+    for (int i = 0; i < t->S; i++) tmp[i] = s[t->perm[move][i]];
+    memcpy(out, tmp, t->S);
+}
+
+/* isSolved_3 (py333.py:229-233): every face equals its FIRST sticker (not its centre,
+ * not the canonical colour). */
+int orc_is_solved(int cube_size, const uint8_t *s)
+{
+    const orc_tables *t = &T[cube_size];
+    for (int f = 0; f < 6; f++)
+        for (int k = 1; k < t->face; k++)
+            if (s[f * t->face + k] != s[f * t->face]) return 0;
+    return 1;
+}
+
+/* getOP_3 (py333.py:224-227): hash the colours at each slot's stickers with weights
+ * [1,2,10] (corners) / [1,10] (edges), look (piece, orientation) up; rows 0..7 corners,
+ * 8..19 edges.  A hash beyond the table is an IndexError in the reference; the oracle
+ * returns -1 (callers never pass such colourings). */
+int orc_get_op(int cube_size, const uint8_t *s, uint8_t *op /* [slots][2] */)
+{
+    const orc_tables *t = &T[cube_size];
+    int r = 0;
+    for (int p = 0; p < t->n_corner; p++, r++) {
+        int h = s[t->corner_defs[p][0]] + 2 * s[t->corner_defs[p][1]] + 10 * s[t->corner_defs[p][2]];
+        if (h >= t->corner_rows) return -1;
+        op[2 * r] = t->corner_lut[h][0]; op[2 * r + 1] = t->corner_lut[h][1];
+    }
+    for (int p = 0; p < t->n_edge; p++, r++) {
+        int h = s[t->edge_defs[p][0]] + 10 * s[t->edge_defs[p][1]];
+        if (h >= t->edge_rows) return -1;
+        op[2 * r] = t->edge_lut[h][0]; op[2 * r + 1] = t->edge_lut[h][1];
+    }
+    return 0;
+}
+
+/* One-hot state.
+ * 3x3x3: pos_to_state_3 (py333.py:235-246): [20][24], row = slot, column = piece*3+ori for
+ *        the 8 corner slots, piece*2+ori for the 12 edge slots.
+ * 2x2x2: CubeEnv.sim_state_to_state (cube_env.py:142-147): [7][21], row = piece,
+ *        column = slot*3+ori.
+ * Also returns the compact code per slot (piece*3+ori / piece*2+ori). */
+int orc_onehot(int cube_size, const uint8_t *s, uint8_t *onehot /* [R*C] or NULL */, uint8_t *code /* [slots] or NULL */)
+{
+    const orc_tables *t = &T[cube_size];
+    uint8_t op[ORC_MAX_SLOTS * 2];
+    if (orc_get_op(cube_size, s, op)) return -1;
+    int slots = t->n_corner + t->n_edge;
+    int C = cube_size == 3 ? 24 : 21, R = cube_size == 3 ? 20 : 7;
+    if (onehot) memset(onehot, 0, (size_t)R * C);
+    for (int p = 0; p < slots; p++) {
+        int mult = p < t->n_corner ? 3 : 2;
+        int v = op[2 * p] * mult + op[2 * p + 1];
+        if (code) code[p] = (uint8_t)v;
+        if (onehot) {
+            if (cube_size == 3) onehot[p * C + v] = 1;
+            else onehot[op[2 * p] * C + p * 3 + op[2 * p + 1]] = 1;
+        }
+    }
+    return 0;
+}
+
+/* CubeEnv.step (cube_env.py:71-111) for a batch of independent cubes, one after the other:
+ * move, one-hot, solved -> reward +1.0 / -1.0, done.  states [n][S] updated in place. */
+int orc_step_batch(int cube_size, uint8_t *states, const uint8_t *actions, int64_t n,
+                   uint8_t *code /* [n][slots] or NULL */, uint8_t *done /* [n] or NULL */, float *reward /* [n] or NULL */,
+                   int threads)
+{
+    const orc_tables *t = &T[cube_size];
+    int slots = t->n_corner + t->n_edge, bad = 0;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(static) reduction(| : bad)
+#endif
+    for (int64_t i = 0; i < n; i++) {
+        uint8_t *s = states + i * t->S;
+        if (actions[i] >= t->A) { bad = 1; continue; }           /* IndexError, cube_env.py:96 */
+        orc_do_move(cube_size, s, actions[i], s);
+        if (code && orc_onehot(cube_size, s, NULL, code + i * slots)) bad = 1;
+        int sol = orc_is_solved(cube_size, s);
+        if (done) done[i] = (uint8_t)sol;
+        if (reward) reward[i] = sol ? 1.0f : -1.0f;
+    }
+    return bad ? -1 : 0;
+}
+
+/* Child expansion = the env work of get_target_value's loop (cube_env.py:212-236) and of
+ * MCTS.expand (/root/reference/mcts.py:96-101): every action applied to the same parent. */
+int orc_expand_batch(int cube_size, const uint8_t *parents, int64_t n,
+                     uint8_t *children /* [n][A][S] */, uint8_t *child_code /* [n][A][slots] or NULL */,
+                     uint8_t *child_solved /* [n][A] */, int threads)
+{
+    const orc_tables *t = &T[cube_size];
+    int slots = t->n_corner + t->n_edge, bad = 0;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(static) reduction(| : bad)
+#endif
+    for (int64_t i = 0; i < n; i++)
+        for (int a = 0; a < t->A; a++) {
+            uint8_t *c = children + (i * t->A + a) * t->S;
+            orc_do_move(cube_size, parents + i * t->S, a, c);
+            if (child_code && orc_onehot(cube_size, c, NULL, child_code + (i * t->A + a) * slots)) bad = 1;
+            child_solved[i * t->A + a] = (uint8_t)orc_is_solved(cube_size, c);
+        }
+    return bad ? -1 : 0;
+}
+
+/* ---- the build's RNG specification (DESIGN.md "RNG"), restated independently ---------- */
+static uint64_t sm64_next(uint64_t *st)
+{
+    uint64_t z = (*st += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+void orc_walk_rng_seed(uint64_t seed, uint64_t stream, uint64_t walk, uint64_t s[2])
+{
+    uint64_t st = seed;
+    uint64_t a = sm64_next(&st);
+    st = a ^ stream;
+    uint64_t b = sm64_next(&st);
+    st = b ^ walk;
+    s[0] = sm64_next(&st);
+    s[1] = sm64_next(&st);
+    if ((s[0] | s[1]) == 0) s[1] = 0x9E3779B97F4A7C15ull;
+}
+/* xoroshiro128+ (a=24, b=16, c=37); action = high 32 bits * A >> 32 */
+uint32_t orc_walk_rng_action(uint64_t s[2], uint32_t A)
+{
+    uint64_t s0 = s[0], s1 = s[1], r = s0 + s1;
+    s1 ^= s0;
+    s[0] = rotl64(s0, 24) ^ s1 ^ (s1 << 16);
+    s[1] = rotl64(s1, 37);
+    return (uint32_t)(((r >> 32) * (uint64_t)A) >> 32);
+}
+
+/* ADI generator = get_random_samples' env work (cube_env.py:187-194) + get_target_value's
+ * child loop (cube_env.py:212-236), for n_walks walks of `depth` moves from solved.
+ * actions_in != NULL replays the given moves ([n][depth]); otherwise the build's RNG draws them. */
+int orc_adi_generate(int cube_size, uint64_t seed, uint64_t stream, int64_t walk0, int64_t n_walks, int depth,
+                     const uint8_t *actions_in, uint8_t *actions_out /* [n][depth] */,
+                     uint8_t *parents /* [n][depth][S] */, uint8_t *parent_code /* [n][depth][slots] or NULL */,
+                     uint8_t *children /* [n][depth][A][S] or NULL */, uint8_t *child_code /* or NULL */,
+                     uint8_t *child_solved /* [n][depth][A] */, int threads)
+{
+    const orc_tables *t = &T[cube_size];
+    int slots = t->n_corner + t->n_edge, bad = 0;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(static) reduction(| : bad)
+#endif
+    for (int64_t w = 0; w < n_walks; w++) {
+        uint8_t s[ORC_MAX_S], c[ORC_MAX_S];
+        uint64_t rng[2];
+        orc_init_state(cube_size, s);                                    /* cube_env.py:188 */
+        orc_walk_rng_seed(seed, stream, (uint64_t)(walk0 + w), rng);
+        for (int d = 0; d < depth; d++) {
+            int64_t u = w * depth + d;
+            int a = actions_in ? actions_in[u] : (int)orc_walk_rng_action(rng, (uint32_t)t->A);
+            if (a >= t->A) { bad = 1; a = 0; }
+            if (actions_out) actions_out[u] = (uint8_t)a;
+            orc_do_move(cube_size, s, a, s);                              /* cube_env.py:191 */
+            if (parents) memcpy(parents + u * t->S, s, t->S);
+            if (parent_code && orc_onehot(cube_size, s, NULL, parent_code + u * slots)) bad = 1;
+            for (int k = 0; k < t->A; k++) {                              /* cube_env.py:212-236 */
+                orc_do_move(cube_size, s, k, c);
+                if (children) memcpy(children + (u * t->A + k) * t->S, c, t->S);
+                if (child_code && orc_onehot(cube_size, c, NULL, child_code + (u * t->A + k) * slots)) bad = 1;
+                if (child_solved) child_solved[u * t->A + k] = (uint8_t)orc_is_solved(cube_size, c);
+            }
+        }
+    }
+    return bad ? -1 : 0;
+}
+
+/* Timed CPU comparator for bench.py's cpu_baseline: `iters` passes of step (move + solved
+ * [+ code]) over n cubes; returns seconds. */
+double orc_time_steps(int cube_size, uint8_t *states, const uint8_t *actions, int64_t n, int iters,
+                      int with_code, uint8_t *code, uint8_t *done, int threads)
+{
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int it = 0; it < iters; it++)
+        orc_step_batch(cube_size, states, actions, n, with_code ? code : NULL, done, NULL, threads);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE itself.
+
+Runs ONLY in the build container (needs /root/reference, which never travels to the
+GPU box).  The reference is imported in-process, unmodified, behind three harness-side
+shims:
+  1. numpy.int = int            (py333.py:171,182,238 use the removed alias)
+  2. a stub `gym` module         (cube_env.py:1; gym is not installed)
+  3. a stub `assets.py222`       (cube_env.py:8; the file is absent from the reference)
+Nothing from the reference is copied: the fixtures hold inputs (action sequences,
+seeds, stub-model weights) and the outputs the reference computed for them.
+
+    python -B tests/golden/make_golden.py
+
+Fixtures written (all small, np.savez_compressed):
+  tables_333.npz   G1  tables as data (perm table, piece defs, hash weights, LUTs)
+  walks_333.npz    G2+G3 single moves from solved; 1000 random 30-move walks, per step
+                   stickers / one-hot column index / done / reward
+  reset_333.npz    G4  CubeEnv.reset(seed, k) for seeds 0,10..90 x k in 1..30
+  adi_333.npz      G5  get_random_samples / get_target_value with a deterministic
+                   linear stub model (incl. solved-child `break` cases)
+  expand_333.npz   G6  12-child expansion of random leaves (MCTS.expand's env work)
+  encode_333.npz   G7  getOP_3/pos_to_state_3 on arbitrary (unreachable) colourings
+                   whose hashes stay inside the LUTs; isSolved_3 on recoloured cubes
+"""
+import hashlib
+import os
+import sys
+import types
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def import_reference():
+    np.int = int  # shim 1
+    gym = types.ModuleType("gym")  # shim 2
+
+    class Env:  # noqa: D401 - empty base class, as gym.Env is only subclassed
+        pass
+
+    gym.Env = Env
+    sys.modules["gym"] = gym
+    sys.path[:0] = [REF, os.path.join(REF, "gym-cube/gym_cube/envs")]
+    import assets  # noqa: F401  (namespace package of the reference)
+
+    stub = types.ModuleType("assets.py222")  # shim 3
+    for name in ("initState", "getOP", "doMove", "isSolved", "getStickers", "printCube"):
+        setattr(stub, name, None)
+    sys.modules["assets.py222"] = stub
+    import torch
+    import cube_env
+    from assets import py333
+
+    return torch, cube_env, py333
+
+
+def cols_of(onehot):
+    """Column index of the single 1 in each of the 20 rows (py333.py:239-245)."""
+    oh = np.asarray(onehot)
+    assert oh.shape == (20, 24) and (oh.sum(1) == 1).all()
+    return np.argmax(oh, 1).astype(np.uint8)
+
+
+def main():
+    torch, cube_env, py333 = import_reference()
+    torch.set_num_threads(1)
+    dev = torch.device("cpu")
+    A = 12
+    names = ["U", "U'", "F", "F'", "R", "R'", "D", "D'", "B", "B'", "L", "L'"]
+
+    # ---------------------------------------------------------------- G1 tables
+    env = cube_env.CubeEnv(dev, cube_size=3)
+    assert env.action_to_sim_action[3] == names
+    assert [py333.moveInds[n] for n in names] == list(range(12))
+    np.savez_compressed(
+        os.path.join(HERE, "tables_333.npz"),
+        moveDefs=py333.moveDefs.astype(np.uint8),
+        corner_pieceDefs=py333.corner_pieceDefs.astype(np.uint8),
+        edge_pieceDefs=py333.edge_pieceDefs.astype(np.uint8),
+        corner_hashOP=py333.corner_hashOP.astype(np.uint8),
+        edge_hashOP=py333.edge_hashOP.astype(np.uint8),
+        corner_pieceInds=py333.corner_pieceInds.astype(np.uint8),
+        edge_pieceInds=py333.edge_pieceInds.astype(np.uint8),
+        initState=py333.initState_3().astype(np.uint8),
+        action_names=np.array(names),
+        state_dim=np.array(env.state_dim),
+        action_dim=np.array(env.action_dim),
+    )
+
+    # ------------------------------------------------- G2 + G3 moves and walks
+    single = np.zeros((A, 54), np.uint8)
+    single_cols = np.zeros((A, 20), np.uint8)
+    single_done = np.zeros(A, np.uint8)
+    for a in range(A):
+        env.init_state()
+        st, r, d, _ = env.step(a)
+        single[a] = env.sim_cube
+        single_cols[a] = cols_of(st)
+        single_done[a] = d
+    W, D = 1000, 30
+    actions = np.random.default_rng(12345).integers(0, A, (W, D), dtype=np.uint8)
+    stickers = np.zeros((W, D, 54), np.uint8)
+    cols = np.zeros((W, D, 20), np.uint8)
+    done = np.zeros((W, D), np.uint8)
+    reward = np.zeros((W, D), np.float32)
+    h = hashlib.sha256()
+    for w in range(W):
+        env.init_state()
+        for d in range(D):
+            st, r, dn, info = env.step(int(actions[w, d]))
+            assert isinstance(r, float) and isinstance(dn, bool) and info == {}
+            stickers[w, d] = env.sim_cube
+            cols[w, d] = cols_of(st)
+            done[w, d] = dn
+            reward[w, d] = r
+            h.update(stickers[w, d].tobytes() + cols[w, d].tobytes() + bytes([int(dn)]))
+    # KAT-D of SURVEY.md section 8c
+    assert h.hexdigest() == "bba6d49d3dac850b34dd2efa3477c7af775612ccd2a229af982e5712dd276649"
+    assert int(done.sum()) == 92
+    # onehot dtype / values as the reference emits them
+    st, _, _, _ = env.step(0)
+    np.savez_compressed(
+        os.path.join(HERE, "walks_333.npz"),
+        single_stickers=single, single_cols=single_cols, single_done=single_done,
+        actions=actions, stickers=stickers, cols=cols, done=done, reward=reward,
+        sha256=np.array(h.hexdigest()), onehot_dtype=np.array(str(st.dtype)),
+    )
+
+    # ------------------------------------------------------------- G4 reset()
+    seeds = np.arange(0, 100, 10)
+    ks = np.arange(1, 31)
+    r_actions = np.full((len(seeds), len(ks), 30), 255, np.uint8)
+    r_stickers = np.zeros((len(seeds), len(ks), 54), np.uint8)
+    r_cols = np.zeros((len(seeds), len(ks), 20), np.uint8)
+    np.random.seed(777)
+    before = np.random.get_state()[1].copy()
+    for i, s in enumerate(seeds):
+        for j, k in enumerate(ks):
+            state = env.reset(seed=int(s), scramble_count=int(k))
+            r_stickers[i, j] = env.sim_cube
+            r_cols[i, j] = cols_of(state)
+            # the action draw itself, reproduced with the same legacy RNG calls
+            np.random.seed(int(s))
+            r_actions[i, j, :k] = np.random.randint(A, size=int(k))
+    np.random.seed(777)
+    assert (np.random.get_state()[1] == before).all()
+    np.savez_compressed(
+        os.path.join(HERE, "reset_333.npz"),
+        seeds=seeds, ks=ks, actions=r_actions, stickers=r_stickers, cols=r_cols,
+    )
+
+    # ---------------------------------------------------------------- G5 ADI
+    rng = np.random.default_rng(99)
+    w_lin = (rng.standard_normal(480) * 0.05).astype(np.float32)
+    b_lin = np.float32(0.125)
+
+    class StubModel(torch.nn.Module):
+        """value = <onehot, w> + b ; policy output unused by the env path."""
+
+        def __init__(self):
+            super().__init__()
+            self.w = torch.tensor(w_lin)
+            self.b = torch.tensor(b_lin)
+
+        def forward(self, x):
+            if x.dim() == 2:
+                x = x.unsqueeze(0)
+            v = x.reshape(x.shape[0], -1) @ self.w + self.b
+            return v.unsqueeze(-1), torch.zeros(x.shape[0], 12)
+
+    class ListBuffer(list):
+        pass
+
+    model = StubModel()
+    temperature = 0.3
+    n_cubes, depth = 64, 30
+    buf = ListBuffer()
+    np.random.seed(2024)
+    env.get_random_samples(buf, model, depth, n_cubes, temperature)
+    np.random.seed(2024)
+    adi_actions = np.stack([np.random.randint(A, size=depth) for _ in range(n_cubes)]).astype(np.uint8)
+    assert len(buf) == n_cubes * depth
+    assert set(buf[0].keys()) == {"state", "target_value", "target_policy", "scramble_count", "error"}
+    adi_cols = np.stack([cols_of(b["state"]) for b in buf]).reshape(n_cubes, depth, 20)
+    adi_tv = np.array([b["target_value"] for b in buf], np.float64).reshape(n_cubes, depth)
+    adi_tp = np.array([b["target_policy"] for b in buf], np.int64).reshape(n_cubes, depth)
+    adi_sc = np.array([b["scramble_count"] for b in buf], np.int64).reshape(n_cubes, depth)
+    adi_err = np.array([b["error"] for b in buf], np.float64).reshape(n_cubes, depth)
+    assert (adi_tv[:, 0] == 1.0).all()  # depth 1: the inverse move solves the cube
+    # dedicated get_target_value cases: 2 moves that cancel etc.
+    np.savez_compressed(
+        os.path.join(HERE, "adi_333.npz"),
+        w=w_lin, b=b_lin, temperature=np.float64(temperature), seed=np.int64(2024),
+        actions=adi_actions, cols=adi_cols, target_value=adi_tv, target_policy=adi_tp,
+        scramble_count=adi_sc, error=adi_err,
+    )
+
+    # ------------------------------------------------------------- G6 expand
+    L = 512
+    leaf_actions = np.random.default_rng(4096).integers(0, A, (L, 20), dtype=np.uint8)
+    leaves = np.zeros((L, 54), np.uint8)
+    ch_st = np.zeros((L, A, 54), np.uint8)
+    ch_cols = np.zeros((L, A, 20), np.uint8)
+    ch_done = np.zeros((L, A), np.uint8)
+    for i in range(L):
+        env.init_state()
+        for a in leaf_actions[i]:
+            env.step(int(a))
+        leaf = env.sim_cube.copy()
+        leaves[i] = leaf
+        for a in range(A):
+            env.sim_cube = leaf.copy()
+            st, r, dn, _ = env.step(a)
+            ch_st[i, a] = env.sim_cube
+            ch_cols[i, a] = cols_of(st)
+            ch_done[i, a] = dn
+    np.savez_compressed(
+        os.path.join(HERE, "expand_333.npz"),
+        leaf_actions=leaf_actions, leaves=leaves, child_stickers=ch_st,
+        child_cols=ch_cols, child_done=ch_done,
+    )
+
+    # ------------------------------------- G7 encode / solved on arbitrary colourings
+    rng = np.random.default_rng(7)
+    arb = []
+    while len(arb) < 2048:
+        s = rng.integers(0, 6, 54)
+        hc = s[py333.corner_pieceDefs] @ py333.corner_hashOP
+        he = s[py333.edge_pieceDefs] @ py333.edge_hashOP
+        if hc.max() < 62 and he.max() < 55:
+            arb.append(s)
+    arb = np.array(arb)
+    arb_cols = np.stack([cols_of(py333.pos_to_state_3(py333.getOP_3(s))) for s in arb])
+    arb_solved = np.array([py333.isSolved_3(s) for s in arb], np.uint8)
+    # recoloured solved cubes: every face uniform but not the canonical colour
+    rec = np.stack([np.repeat(rng.permutation(6), 9) for _ in range(32)])
+    rec = np.concatenate([rec, np.repeat(rng.integers(0, 6, (32, 6)), 9, axis=1)])
+    rec_solved = np.array([py333.isSolved_3(s) for s in rec], np.uint8)
+    np.savez_compressed(
+        os.path.join(HERE, "encode_333.npz"),
+        stickers=arb.astype(np.uint8), cols=arb_cols, solved=arb_solved,
+        recoloured=rec.astype(np.uint8), recoloured_solved=rec_solved,
+    )
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,192 @@
+"""The oracle (oracle/) against every golden vector captured from the reference (CPU only)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle.oracle_np import OracleCubeEnv, tables_222
+
+
+def test_g2_single_moves(oracle, golden):
+    g = golden("walks_333")
+    st, code, done, rew = oracle.step(3, oracle.solved(3, 12), np.arange(12))
+    assert (st == g["single_stickers"]).all()
+    assert (code == g["single_cols"]).all()
+    assert (done == g["single_done"]).all() and (rew == -1.0).all()
+
+
+def test_g3_walks_c(oracle, golden):
+    g = golden("walks_333")
+    W, D = g["actions"].shape
+    st = oracle.solved(3, W)
+    h = []
+    for d in range(D):
+        st, code, done, rew = oracle.step(3, st, g["actions"][:, d])
+        assert (st == g["stickers"][:, d]).all()
+        assert (code == g["cols"][:, d]).all()
+        assert (done == g["done"][:, d]).all()
+        assert (rew == g["reward"][:, d]).all()
+        h.append((st, code, done))
+    # KAT-D: sha256 over per-step stickers|cols|done in walk-major order
+    sha = hashlib.sha256()
+    for w in range(W):
+        for d in range(D):
+            sha.update(h[d][0][w].tobytes() + h[d][1][w].tobytes() + bytes([int(h[d][2][w])]))
+    assert sha.hexdigest() == str(g["sha256"])
+    assert int(g["done"].sum()) == 92
+
+
+def test_g3_walks_adi_replay(oracle, golden):
+    g = golden("walks_333")
+    out = oracle.adi(3, 64, 30, actions_in=g["actions"][:64])
+    assert (out["parents"] == g["stickers"][:64]).all()
+    assert (out["parent_code"] == g["cols"][:64]).all()
+    assert (out["actions"] == g["actions"][:64]).all()
+
+
+def test_g3_walks_numpy_env(golden):
+    g = golden("walks_333")
+    env = OracleCubeEnv(None, 3)
+    for w in range(40):
+        env.init_state()
+        for d in range(30):
+            s, r, dn, info = env.step(int(g["actions"][w, d]))
+            assert (env.sim_cube == g["stickers"][w, d]).all()
+            assert (np.argmax(s, 1) == g["cols"][w, d]).all() and (s.sum(1) == 1).all()
+            assert dn == bool(g["done"][w, d]) and r == g["reward"][w, d] and info == {}
+    assert str(s.dtype) == str(g["onehot_dtype"])
+
+
+def test_kat_abc():
+    env = OracleCubeEnv(None, 3)
+    for a in (4, 0, 5, 1):  # R U R' U'
+        s, r, d, _ = env.step(a)
+    assert "".join(map(str, env.sim_cube)) == "004002002110511011223220222331333333544444444511555555"
+    assert np.argmax(s, 1).tolist() == [9, 3, 20, 1, 12, 15, 7, 21, 6, 2, 4, 18, 8, 10, 12, 14, 16, 0, 20, 22]
+    assert r == -1.0
+    env.init_state()
+    assert env.step(0)[1:3] == (-1.0, False) and env.step(1)[1:3] == (1.0, True)
+
+
+def test_g4_reset(golden):
+    g = golden("reset_333")
+    env = OracleCubeEnv(None, 3)
+    np.random.seed(4242)
+    before = np.random.get_state()[1].copy()
+    for i, seed in enumerate(g["seeds"]):
+        for j, k in enumerate(g["ks"]):
+            s = env.reset(seed=int(seed), scramble_count=int(k))
+            assert (env.sim_cube == g["stickers"][i, j]).all()
+            assert (np.argmax(s, 1) == g["cols"][i, j]).all()
+    assert (np.random.get_state()[1] == before).all()  # cube_env.py:62,68
+    with pytest.raises(UnboundLocalError):
+        env.reset(seed=1, scramble_count=0)  # reference quirk
+
+
+def test_g4_reset_actions_c(oracle, golden):
+    g = golden("reset_333")
+    for i in range(len(g["seeds"])):
+        k = 30
+        out = oracle.adi(3, 1, k, actions_in=g["actions"][i, k - 1][None, :k])
+        assert (out["parents"][0, -1] == g["stickers"][i, k - 1]).all()
+
+
+def _stub_model(g):
+    import torch
+
+    w, b = torch.tensor(g["w"]), torch.tensor(g["b"])
+
+    def model(x):
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+        return (x.reshape(x.shape[0], -1) @ w + b).unsqueeze(-1), None
+    return model
+
+
+def test_g5_adi_numpy_env(golden):
+    g = golden("adi_333")
+    env = OracleCubeEnv(None, 3)
+    buf = []
+    np.random.seed(int(g["seed"]))
+    n = 8
+    env.get_random_samples(buf, _stub_model(g), 30, n, float(g["temperature"]))
+    assert len(buf) == n * 30
+    for i, smp in enumerate(buf):
+        c, d = divmod(i, 30)
+        assert (np.argmax(smp["state"], 1) == g["cols"][c, d]).all()
+        assert smp["target_policy"] == g["target_policy"][c, d]
+        assert smp["scramble_count"] == g["scramble_count"][c, d] == d + 1
+        assert smp["target_value"] == pytest.approx(g["target_value"][c, d], abs=1e-5)
+        assert smp["error"] == pytest.approx(g["error"][c, d], abs=1e-5)
+
+
+def test_g5_adi_c_children(oracle, golden):
+    """Solved-child override and child codes via the C oracle + the stub model in numpy."""
+    g = golden("adi_333")
+    out = oracle.adi(3, *g["actions"].shape, actions_in=g["actions"])
+    assert (out["parent_code"] == g["cols"]).all()
+    w = g["w"].reshape(20, 24).astype(np.float64)
+    cc = out["child_code"].astype(np.int64)  # [n, d, 12, 20]
+    v = w[np.arange(20), cc].sum(-1) + float(g["b"]) - 1.0
+    solved = out["child_solved"].astype(bool)
+    first = np.argmax(solved, -1)
+    tp = np.where(solved.any(-1), first, np.argmax(v, -1))
+    tv = np.where(solved.any(-1), 1.0, v.max(-1))
+    gap = np.sort(v, -1)
+    safe = (gap[..., -1] - gap[..., -2] > 1e-5) | solved.any(-1)
+    assert (tp[safe] == g["target_policy"][safe]).all() and safe.mean() > 0.99
+    assert np.allclose(tv, g["target_value"], atol=1e-5)
+    assert (g["target_value"][:, 0] == 1.0).all()
+
+
+def test_g6_expand(oracle, golden):
+    g = golden("expand_333")
+    ch, cc, cs = oracle.expand(3, g["leaves"])
+    assert (ch == g["child_stickers"]).all()
+    assert (cc == g["child_cols"]).all()
+    assert (cs == g["child_done"]).all()
+    out = oracle.adi(3, len(g["leaves"]), 20, actions_in=g["leaf_actions"])
+    assert (out["parents"][:, -1] == g["leaves"]).all()
+
+
+def test_g7_encode_arbitrary(oracle, golden):
+    g = golden("encode_333")
+    code, oh = oracle.encode(3, g["stickers"])
+    assert (code == g["cols"]).all()
+    assert (oh.sum(-1) == 1).all() and (np.argmax(oh, -1) == g["cols"]).all()
+    assert (oracle.is_solved(3, g["stickers"]) == g["solved"]).all()
+    assert (oracle.is_solved(3, g["recoloured"]) == g["recoloured_solved"]).all()
+    assert g["recoloured_solved"][:32].all()  # uniform faces count as solved whatever the colour
+
+
+def test_222_unpinned_properties(oracle):
+    """2x2x2 has no reference vectors (parity unpinned): structural properties only."""
+    t = tables_222()
+    assert t["perm"].shape == (6, 24)
+    fixed = [i for i in range(24) if all(t["perm"][a][i] == i for a in range(6))]
+    assert fixed == [14, 18, 23]
+    env = OracleCubeEnv(None, 2)
+    assert env.state_dim == [7, 21] and env.action_dim == 6
+    s = env.reset(seed=3, scramble_count=20)
+    assert s.shape == (7, 21) and s.dtype == np.float64
+    assert (s.sum(1) == 1).all() and (s.reshape(7, 7, 3).sum((0, 2)) == 1).all()
+    env.init_state()
+    assert np.argmax(env.cube, 1).tolist() == [0, 3, 6, 9, 12, 15, 18]
+    for a in (4, 0, 5, 1) * 6:  # (R U R' U')^6 = identity
+        _, r, d, _ = env.step(a)
+    assert d and r == 1.0
+    st = oracle.solved(2, 4)
+    for a in (4, 0, 5, 1) * 6:
+        st, code, done, rew = oracle.step(2, st, np.full(4, a))
+    assert done.all()
+
+
+def test_rng_spec(oracle):
+    a = oracle.rng_actions(2024, 0, 0, 4096, 12)
+    assert a.max() == 11 and a.min() == 0
+    assert np.bincount(a, minlength=12).min() > 250
+    assert not (a[:64] == oracle.rng_actions(2024, 1, 0, 64, 12)).all()
+    assert not (a[:64] == oracle.rng_actions(2024, 0, 1, 64, 12)).all()
+    out = oracle.adi(3, 8, 16, seed=2024, stream=0, walk0=0)
+    assert (out["actions"][0] == a[:16]).all()
+    assert (out["actions"][5] == oracle.rng_actions(2024, 0, 5, 16, 12)).all()

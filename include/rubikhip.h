@@ -1,0 +1,161 @@
+/*
+ * rubikhip.h -- C ABI of librubikhip.so: the MI355X (gfx950) cube-environment hot path.
+ *
+ * The reference (SUNGBEOMCHOI/Rubiks-Cube-Solver) has no FFI: its env path is Python
+ * (SURVEY.md section 8b).  Each entry point below names the reference code it replaces,
+ * paths relative to /root/reference.  A binding only needs plain pointers and sizes; see
+ * INTEGRATION.md for the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - All buffers are DEVICE memory owned by the caller (e.g. PyTorch-ROCm tensors); the
+ *     library allocates nothing but its constant tables and one status word per device.
+ *   - Cube states are structure-of-arrays uint8: sticker s of cube n lives at
+ *     st[s * pitch + n]; S = 54 (cube_size 3) or 24 (cube_size 2) rows; values 0..5.
+ *     pitch >= n_cubes, pitch % 16 == 0, base pointers 16-byte aligned.
+ *   - actions are uint8 in the env's action order U,U',F,F',R,R'[,D,D',B,B',L,L']
+ *     (gym-cube/gym_cube/envs/cube_env.py:24-28); A = 12 | 6.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
+ *     stream-ordered, never synchronise (except rc_read_status / rc_get_tables), are
+ *     re-entrant, and keep no mutable state besides the per-device status word.
+ *   - Return value: RC_OK or a negative RC_E* code; rc_last_error() gives the message of
+ *     the calling thread's last failure.  Nothing is thrown across the ABI.
+ *   - Out-of-range actions are the reference's IndexError (cube_env.py:86,96).  On the
+ *     device they cannot raise: the cube is left in an unspecified (in-bounds) state and
+ *     bit RC_STATUS_BAD_ACTION of the status word is set; rc_read_status() reports it.
+ *
+ * One-hot formats (`fmt`)
+ *   RC_FMT_NONE   nothing written
+ *   RC_FMT_CODE   compact, lossless: uint8 code[slot * pitch + n], slot = 0..19 | 0..6,
+ *                 code = piece*3+ori (corner slots) or piece*2+ori (edge slots)
+ *                 (getOP_3, assets/py333.py:224-227).  3x3x3: one-hot column of row `slot`
+ *                 (pos_to_state_3, py333.py:235-246).  2x2x2: row = code/3,
+ *                 column = slot*3 + code%3 (cube_env.py:142-147).
+ *   RC_FMT_U8 / RC_FMT_F16 / RC_FMT_F32
+ *                 dense [n][R][C] (R,C = 20,24 | 7,21), contiguous per cube, values {0,1}:
+ *                 exactly what model.py:31-45 consumes after `.float()`.
+ */
+#ifndef RUBIKHIP_H
+#define RUBIKHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RC_OK 0
+#define RC_EINVAL (-1)    /* bad argument (null, alignment, cube_size, fmt, sizes) */
+#define RC_EHIP (-2)      /* a HIP runtime call failed */
+#define RC_ENODEV (-3)    /* rc_init not called / no gfx950 device */
+
+#define RC_FMT_NONE 0
+#define RC_FMT_CODE 1
+#define RC_FMT_U8 2
+#define RC_FMT_F16 3
+#define RC_FMT_F32 4
+
+#define RC_STATUS_BAD_ACTION 1u
+
+/* Library / ABI version (major*100 + minor). */
+int rc_version(void);
+
+/* Select `device` for the calling thread's later calls and make the code object resident.
+ * Idempotent.  Replaces: importing py333 (module-level table construction,
+ * gym-cube/gym_cube/envs/assets/py333.py:41-198). */
+int rc_init(int device);
+
+/* Host copies of the tables the kernels use (any pointer may be NULL).
+ *   perm        [A][S]   new[i] = old[perm[a][i]]            (py333.py:46-138 moveDefs)
+ *   solved      [S]                                           (py333.py:211-218)
+ *   corner_defs [NC][3], edge_defs [NE][2]                    (py333.py:140-164)
+ *   corner_code [72], edge_code [72]  hash -> piece*3+ori / piece*2+ori, 0 where the
+ *                reference table has no entry or ends        (py333.py:171-198)
+ * dims, if non-NULL, receives {S, A, NC, NE, R, C}. */
+int rc_get_tables(int cube_size, uint8_t *perm, uint8_t *solved, uint8_t *corner_defs,
+                  uint8_t *edge_defs, uint8_t *corner_code, uint8_t *edge_code, int32_t dims[6]);
+
+/* st[s][n] = s / face_size for n < n_cubes.  Replaces initState_3 (py333.py:211-218) /
+ * CubeEnv.init_state (cube_env.py:33-42). */
+int rc_fill_solved(uint8_t *st, int64_t n_cubes, int64_t pitch, int cube_size, void *stream);
+
+/* One env step for n_cubes independent cubes: out = in moved by actions[n], then
+ * done[n] = solved, reward[n] = done ? +1.0f : -1.0f, and the one-hot of the NEW state.
+ * `out` may alias `in` (in-place); reward, done, onehot may be NULL (onehot NULL requires
+ * fmt RC_FMT_NONE).  code_pitch is the row pitch of an RC_FMT_CODE buffer (ignored for
+ * dense formats).  Replaces CubeEnv.step (cube_env.py:71-111) = doMove_3 (py333.py:220-222)
+ * + sim_state_to_state (cube_env.py:132-152) + isSolved_3 (py333.py:229-233). */
+int rc_apply_moves(const uint8_t *in, uint8_t *out, const uint8_t *actions, int64_t n_cubes,
+                   int64_t pitch_in, int64_t pitch_out, int cube_size, float *reward,
+                   uint8_t *done, void *onehot, int fmt, int64_t code_pitch, void *stream);
+
+/* `depth` moves applied in place to every cube: the scramble loop of CubeEnv.reset
+ * (cube_env.py:65-67) for n_cubes cubes at once.  actions_in[d * act_pitch + n] replays given
+ * moves (e.g. the host's legacy-numpy draws, for bit-exact reset(seed)); NULL draws them on
+ * the device exactly like rc_adi_generate (walk = walk_offset + n).  actions_out (same layout,
+ * NULL to skip) receives the moves used.  done/reward (NULL to skip) describe the final state. */
+int rc_scramble(uint8_t *st, int64_t n_cubes, int64_t pitch, int cube_size, int depth, uint64_t seed,
+                uint64_t stream_id, int64_t walk_offset, const uint8_t *actions_in, uint8_t *actions_out,
+                int64_t act_pitch, uint8_t *done, float *reward, void *stream);
+
+/* done / reward of the given states, no move.  Replaces isSolved_3 (py333.py:229-233). */
+int rc_is_solved(const uint8_t *st, int64_t n_cubes, int64_t pitch, int cube_size,
+                 uint8_t *done, float *reward, void *stream);
+
+/* One-hot of the given states, no move.  Replaces sim_state_to_state (cube_env.py:132-152)
+ * = pos_to_state_3(getOP_3(s)) (py333.py:224-246). */
+int rc_encode(const uint8_t *st, int64_t n_cubes, int64_t pitch, int cube_size, void *onehot,
+              int fmt, int64_t code_pitch, void *stream);
+
+/* Dense one-hot [n][R][C] from a compact code buffer (RC_FMT_CODE layout). fmt = U8/F16/F32. */
+int rc_onehot_from_code(const uint8_t *code, int64_t n_cubes, int64_t code_pitch, int cube_size,
+                        void *onehot, int fmt, void *stream);
+
+/* All A children of every cube: children[(a*S + s) * pitch_out + n], child_solved[a * pitch_out + n],
+ * child_code[(a*SLOTS + slot) * pitch_out + n] (NULL to skip).  Replaces the child loops of
+ * CubeEnv.get_target_value (cube_env.py:212-236) and MCTS.expand (mcts.py:96-101). */
+int rc_expand_children(const uint8_t *in, int64_t n_cubes, int64_t pitch_in, int cube_size,
+                       uint8_t *children, uint8_t *child_solved, uint8_t *child_code,
+                       int64_t pitch_out, void *stream);
+
+/* ADI scramble generator: n_walks random walks of `depth` moves from the solved cube, each
+ * step expanded to all A children.  Replaces the env work of CubeEnv.get_random_samples
+ * (cube_env.py:177-194) + get_target_value's child loop (cube_env.py:212-236).
+ *   actions_in   NULL: moves are drawn on the device, walk w (global index walk_offset + w)
+ *                uses xoroshiro128+ seeded by splitmix64 from (seed, stream_id, walk)
+ *                (DESIGN.md "RNG"); non-NULL: replay actions_in[d * pitch + w].
+ *   actions_out  [depth][pitch]                 (NULL to skip)
+ *   parents      [depth][S][pitch]              (NULL to skip)
+ *   parent_code  [depth][SLOTS][pitch]          (NULL to skip)
+ *   children     [depth][A][S][pitch]           (NULL to skip)
+ *   child_code   [depth][A][SLOTS][pitch]       (NULL to skip)
+ *   child_solved [depth][A][pitch]              (NULL to skip)
+ * pitch >= n_walks, pitch % 16 == 0. */
+int rc_adi_generate(uint64_t seed, uint64_t stream_id, int64_t walk_offset, int64_t n_walks,
+                    int depth, int cube_size, int64_t pitch, const uint8_t *actions_in,
+                    uint8_t *actions_out, uint8_t *parents, uint8_t *parent_code,
+                    uint8_t *children, uint8_t *child_code, uint8_t *child_solved, void *stream);
+
+/* ADI target assembly for `n` parents with A children each.
+ * Replaces cube_env.py:229-232,239-251:
+ *   if any child is solved: target_value = 1.0, target_policy = lowest solved index;
+ *   else target_value = max_a(child_value[a] + (-1.0f)), target_policy = first arg max;
+ *   error = |double(parent_value) - double(target_value)| * weight[n]   (weight = d**-T, host).
+ * child_value[a * pitch + n] (float), child_solved[a * pitch + n], parent_value[n]. */
+int rc_adi_targets(const float *child_value, const uint8_t *child_solved, const float *parent_value,
+                   const double *weight, int64_t n, int64_t pitch, int cube_size,
+                   float *target_value, int32_t *target_policy, double *error, void *stream);
+
+/* Read-and-clear the device status word (synchronises `stream`). */
+int rc_read_status(uint32_t *status, void *stream);
+
+/* Message of the calling thread's last failed call ("" if none). */
+const char *rc_last_error(void);
+
+/* Tuning knob for benchmarks/tests: selects a kernel variant for rc_apply_moves
+ * (0 = default).  See DESIGN.md "Kernel variants". */
+int rc_set_variant(int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUBIKHIP_H */

@@ -1,0 +1,128 @@
+"""ctypes binding of librubikhip.so (include/rubikhip.h) over PyTorch-ROCm tensors.
+
+PyTorch is plumbing only: it owns the device buffers and the HIP stream; every cube
+operation is a kernel of librubikhip.so.  There is NO fallback: if the library is missing
+or was not built, importing this module's `lib()` raises, loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import torch  # must be imported before the library so both share one HIP runtime (libamdhip64.so.7)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librubikhip.so")
+
+FMT_NONE, FMT_CODE, FMT_U8, FMT_F16, FMT_F32 = 0, 1, 2, 3, 4
+_FMT_DTYPE = {FMT_U8: torch.uint8, FMT_F16: torch.float16, FMT_F32: torch.float32}
+STATUS_BAD_ACTION = 1
+
+_lock = threading.Lock()
+_lib = None
+_inited = set()
+
+
+class RubikHipError(RuntimeError):
+    pass
+
+
+def _declare(L):
+    vp, i64, i32, u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64
+    L.rc_version.restype = i32
+    L.rc_last_error.restype = ctypes.c_char_p
+    L.rc_init.argtypes = [i32]
+    L.rc_set_variant.argtypes = [i32]
+    L.rc_get_tables.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
+    L.rc_fill_solved.argtypes = [vp, i64, i64, i32, vp]
+    L.rc_apply_moves.argtypes = [vp, vp, vp, i64, i64, i64, i32, vp, vp, vp, i32, i64, vp]
+    L.rc_scramble.argtypes = [vp, i64, i64, i32, i32, u64, u64, i64, vp, vp, i64, vp, vp, vp]
+    L.rc_is_solved.argtypes = [vp, i64, i64, i32, vp, vp, vp]
+    L.rc_encode.argtypes = [vp, i64, i64, i32, vp, i32, i64, vp]
+    L.rc_onehot_from_code.argtypes = [vp, i64, i64, i32, vp, i32, vp]
+    L.rc_expand_children.argtypes = [vp, i64, i64, i32, vp, vp, vp, i64, vp]
+    L.rc_adi_generate.argtypes = [u64, u64, i64, i64, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.rc_adi_targets.argtypes = [vp, vp, vp, vp, i64, i64, i32, vp, vp, vp, vp]
+    L.rc_read_status.argtypes = [vp, vp]
+    for name in ("rc_init", "rc_set_variant", "rc_get_tables", "rc_fill_solved", "rc_apply_moves", "rc_scramble", "rc_is_solved",
+                 "rc_encode", "rc_onehot_from_code", "rc_expand_children", "rc_adi_generate", "rc_adi_targets",
+                 "rc_read_status"):
+        getattr(L, name).restype = i32
+
+
+def lib():
+    """The loaded library (loads on first use).  Raises if it was not built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RubikHipError(
+                        f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+                L = ctypes.CDLL(LIB_PATH)
+                _declare(L)
+                _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RubikHipError(f"librubikhip error {rc}: {lib().rc_last_error().decode()}")
+
+
+def init(device: torch.device):
+    """rc_init for the tensor's device (once per device per process)."""
+    if device.type != "cuda":
+        raise RubikHipError(f"cube tensors must live on a HIP device, got {device}")
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _inited:
+        check(lib().rc_init(idx))
+        _inited.add(idx)
+    return idx
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def pitch_for(n: int, align: int = 256) -> int:
+    """Row pitch: >= n, multiple of `align` bytes (256 keeps every row segment line-aligned)."""
+    return max(align, (n + align - 1) // align * align)
+
+
+def dense_dtype(fmt):
+    return _FMT_DTYPE[fmt]
+
+
+def fmt_of(dtype):
+    for f, d in _FMT_DTYPE.items():
+        if d == dtype:
+            return f
+    raise RubikHipError(f"no dense one-hot format for dtype {dtype}")
+
+
+def read_status(device=None) -> int:
+    out = ctypes.c_uint32(0)
+    check(lib().rc_read_status(ctypes.byref(out), stream_ptr(device)))
+    return out.value
+
+
+def get_tables(cube_size):
+    """Host copy of the tables baked into the library (for tests: same numbers as tables.py)."""
+    import numpy as np
+
+    dims = (ctypes.c_int32 * 6)()
+    check(lib().rc_get_tables(cube_size, None, None, None, None, None, None, dims))
+    S, A, NC, NE, R, C = list(dims)
+    out = dict(perm=np.zeros((A, S), np.uint8), solved=np.zeros(S, np.uint8), corner_defs=np.zeros((NC, 3), np.uint8),
+               edge_defs=np.zeros((max(NE, 1), 2), np.uint8), corner_code=np.zeros(72, np.uint8), edge_code=np.zeros(72, np.uint8))
+    check(lib().rc_get_tables(cube_size, *(v.ctypes.data_as(ctypes.c_void_p) for v in out.values()), dims))
+    out["edge_defs"] = out["edge_defs"][:NE]
+    out["dims"] = (S, A, NC, NE, R, C)
+    return out

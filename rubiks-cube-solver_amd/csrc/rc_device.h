@@ -1,0 +1,386 @@
+// rc_device.h -- device-side building blocks of the cube hot path (gfx950 / CDNA4 only).
+//
+// Everything works on PACKED bytes: one 32-bit register holds the same sticker (or action,
+// or code) of 4 consecutive cubes, a lane carries V such registers per row (4*V cubes), so a
+// wavefront moves 256*V cubes at once and every global access is a coalesced row segment
+// of the structure-of-arrays state.  A face turn is then a network of v_bfi_b32 selects
+// driven by per-byte action masks (one v_perm_b32 each); no LDS, no per-byte gathers.
+//
+// Reference semantics restated here (paths relative to /root/reference/gym-cube/gym_cube/envs):
+//   apply_move  : doMove_3,  assets/py333.py:220-222   new[i] = old[moveDefs[a][i]]
+//   unsolved    : isSolved_3, assets/py333.py:229-233  every face equals its first sticker
+//   encode      : getOP_3 + pos_to_state_3, assets/py333.py:224-246 (hash, LUT, column)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <utility>
+
+#include "rc_tables.h"
+
+namespace rc {
+
+// ---------------------------------------------------------------- compile-time loops
+template <class F, int... I>
+__device__ __forceinline__ void sfor_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void sfor(F &&f) {
+    sfor_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// perm[a][i] expanded at compile time from the 4-cycles of rc_tables.h
+template <class T>
+struct PermTable {
+    uint8_t v[T::A][T::S];
+    constexpr PermTable() : v{} {
+        for (int a = 0; a < T::A; ++a)
+            for (int i = 0; i < T::S; ++i) v[a][i] = (uint8_t)i;
+        for (int f = 0; f < T::A / 2; ++f)
+            for (int c = 0; c < T::NCYC; ++c)
+                for (int k = 0; k < 4; ++k) {
+                    const uint8_t src = T::turn[f][c][k], dst = T::turn[f][c][(k + 1) & 3];
+                    v[2 * f][dst] = src;      // clockwise: content of src arrives at dst
+                    v[2 * f + 1][src] = dst;  // counter-clockwise: the inverse
+                }
+    }
+};
+template <class T>
+inline constexpr PermTable<T> kPerm{};
+
+// slot touched by action a?  (a slot is touched when any of its stickers moves)
+template <class T>
+constexpr bool slot_moves(int a, int slot) {
+    if (slot < T::NC) {
+        for (int k = 0; k < 3; ++k)
+            if (kPerm<T>.v[a][T::cdef[slot][k]] != T::cdef[slot][k]) return true;
+    } else {
+        for (int k = 0; k < 2; ++k)
+            if (kPerm<T>.v[a][T::edef[slot - T::NC][k]] != T::edef[slot - T::NC][k]) return true;
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------ packed registers
+template <int V>
+struct Pk {
+    uint32_t d[V];
+};
+
+#define RC_V _Pragma("unroll") for (int k = 0; k < V; ++k)
+
+template <int V> __device__ __forceinline__ Pk<V> splat(uint32_t x) { Pk<V> r; RC_V r.d[k] = x; return r; }
+template <int V> __device__ __forceinline__ Pk<V> operator^(Pk<V> a, Pk<V> b) { Pk<V> r; RC_V r.d[k] = a.d[k] ^ b.d[k]; return r; }
+template <int V> __device__ __forceinline__ Pk<V> operator|(Pk<V> a, Pk<V> b) { Pk<V> r; RC_V r.d[k] = a.d[k] | b.d[k]; return r; }
+template <int V> __device__ __forceinline__ Pk<V> operator&(Pk<V> a, uint32_t c) { Pk<V> r; RC_V r.d[k] = a.d[k] & c; return r; }
+template <int V> __device__ __forceinline__ Pk<V> shl(Pk<V> a, int s) { Pk<V> r; RC_V r.d[k] = a.d[k] << s; return r; }
+// (a << s) + b  -> v_lshl_add_u32
+template <int V> __device__ __forceinline__ Pk<V> shl_add(Pk<V> a, int s, Pk<V> b) { Pk<V> r; RC_V r.d[k] = (a.d[k] << s) + b.d[k]; return r; }
+// per bit: m ? a : b  -> v_bfi_b32
+template <int V> __device__ __forceinline__ Pk<V> sel(Pk<V> m, Pk<V> a, Pk<V> b) { Pk<V> r; RC_V r.d[k] = (a.d[k] & m.d[k]) | (b.d[k] & ~m.d[k]); return r; }
+template <int V> __device__ __forceinline__ Pk<V> andn(Pk<V> a, Pk<V> m) { Pk<V> r; RC_V r.d[k] = a.d[k] & ~m.d[k]; return r; }
+// v_perm_b32: byte j of the result = bytes {hi:lo}[sel.byte j] for sel 0..7, 0x00 for 12, 0xff for >= 13,
+// 0xff * sign of byte 1/3/5/7 for sel 8/9/10/11
+template <int V> __device__ __forceinline__ Pk<V> perm(uint32_t hi, uint32_t lo, Pk<V> s) { Pk<V> r; RC_V r.d[k] = __builtin_amdgcn_perm(hi, lo, s.d[k]); return r; }
+// 0xff in every byte whose bit 7 is set
+template <int V> __device__ __forceinline__ Pk<V> signmask(Pk<V> x) { Pk<V> r; RC_V r.d[k] = __builtin_amdgcn_perm(x.d[k] << 8, x.d[k], 0x090B080Au); return r; }
+template <int V> __device__ __forceinline__ bool any(Pk<V> a) { uint32_t o = 0; RC_V o |= a.d[k]; return o != 0; }
+
+// ------------------------------------------------------------------ global row access
+template <int V> struct VecT;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <> struct VecT<1> { using type = uint32_t; };
+template <> struct VecT<2> { using type = u32x2; };
+template <> struct VecT<4> { using type = u32x4; };
+
+template <int V, bool NT>
+__device__ __forceinline__ Pk<V> ld(const uint8_t *p) {
+    using U = typename VecT<V>::type;
+    U u;
+    if constexpr (NT) u = __builtin_nontemporal_load(reinterpret_cast<const U *>(p));
+    else u = *reinterpret_cast<const U *>(p);
+    Pk<V> r;
+    __builtin_memcpy(&r, &u, sizeof(U));
+    return r;
+}
+template <int V, bool NT>
+__device__ __forceinline__ void st(uint8_t *p, Pk<V> v) {
+    using U = typename VecT<V>::type;
+    U u;
+    __builtin_memcpy(&u, &v, sizeof(U));
+    if constexpr (NT) __builtin_nontemporal_store(u, reinterpret_cast<U *>(p));
+    else *reinterpret_cast<U *>(p) = u;
+}
+// [n] arrays without padding (actions, done): vector access when the whole pack is inside, bytes otherwise
+template <int V>
+__device__ __forceinline__ Pk<V> ld_tail(const uint8_t *base, int64_t n0, int64_t n, uint32_t fill) {
+    if (n0 + 4 * V <= n) return ld<V, false>(base + n0);
+    Pk<V> r = splat<V>(fill * 0x01010101u);
+    for (int j = 0; j < 4 * V && n0 + j < n; ++j) {
+        r.d[j >> 2] = (r.d[j >> 2] & ~(0xffu << (8 * (j & 3)))) | ((uint32_t)base[n0 + j] << (8 * (j & 3)));
+    }
+    return r;
+}
+template <int V>
+__device__ __forceinline__ void st_tail(uint8_t *base, int64_t n0, int64_t n, Pk<V> v) {
+    if (n0 + 4 * V <= n) { st<V, false>(base + n0, v); return; }
+    for (int j = 0; j < 4 * V && n0 + j < n; ++j) base[n0 + j] = (uint8_t)(v.d[j >> 2] >> (8 * (j & 3)));
+}
+
+// ---------------------------------------------------------------------- action masks
+// m[a] selects (per byte) the cubes whose action is a.  Only the bits a sticker can use
+// (0..2) are guaranteed: mask bytes are 0x07 (a < 8) or 0xff (a >= 8); a stray 0x80 can show
+// for a >= 8 on cubes with an odd action < 8 -- stickers never carry bit 7, so it selects 0 from 0.
+// Returns, per byte, non-zero where the action is not in 0..A-1.
+constexpr uint64_t mask_data(int a) {
+    // a < 8: selector a reads byte a = 0x07; a >= 8: selector a reads the sign of byte 2*(a-8)+1 = 0x80
+    return a < 8 ? (0x07ull << (8 * (a & 7))) : (0x80ull << (8 * (2 * ((a - 8) & 3) + 1)));
+}
+template <class T, int V>
+__device__ __forceinline__ Pk<V> action_masks(Pk<V> act, Pk<V> (&m)[T::A]) {
+    Pk<V> seen = splat<V>(0);
+    sfor<T::A>([&](auto ac) {
+        constexpr int a = decltype(ac)::value;
+        constexpr uint64_t data = mask_data(a);
+        m[a] = perm<V>((uint32_t)(data >> 32), (uint32_t)data, act);
+        seen = seen | m[a];
+    });
+    Pk<V> big = perm<V>(0u, 0u, act);  // 0xff where the byte is >= 13: every mask above read 0xff
+    Pk<V> bad;
+    RC_V bad.d[k] = (~seen.d[k] & 0x07070707u) | big.d[k];
+    return bad;
+}
+
+// ------------------------------------------------------------------------- the move
+template <class T, int V>
+__device__ __forceinline__ void apply_move(const Pk<V> (&in)[T::S], const Pk<V> (&m)[T::A], Pk<V> (&out)[T::S]) {
+    sfor<T::S>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        Pk<V> o = in[i];
+        sfor<T::A>([&](auto ac) {
+            constexpr int a = decltype(ac)::value;
+            constexpr int src = kPerm<T>.v[a][i];
+            if constexpr (src != i) o = sel(m[a], in[src], o);
+        });
+        out[i] = o;
+    });
+}
+
+// child by a FIXED action: pure register renaming
+template <class T, int V, int A_>
+__device__ __forceinline__ void fixed_move(const Pk<V> (&in)[T::S], Pk<V> (&out)[T::S]) {
+    sfor<T::S>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int src = kPerm<T>.v[A_][i];
+        out[i] = in[src];
+    });
+}
+
+// per byte: non-zero iff the cube is NOT solved (py333.py:229-233: compare with the face's first sticker)
+template <class T, int V>
+__device__ __forceinline__ Pk<V> unsolved(const Pk<V> (&s)[T::S]) {
+    Pk<V> acc = splat<V>(0);
+    sfor<6>([&](auto fc) {
+        constexpr int f = decltype(fc)::value;
+        sfor<T::FACE - 1>([&](auto kc) {
+            constexpr int k = decltype(kc)::value + 1;
+            acc = acc | (s[f * T::FACE + k] ^ s[f * T::FACE]);
+        });
+    });
+    return acc;
+}
+// 0x01 per solved cube, 0x00 otherwise
+template <int V>
+__device__ __forceinline__ Pk<V> done_bytes(Pk<V> uns) {
+    Pk<V> r;
+    RC_V {
+        const uint32_t x = uns.d[k];
+        const uint32_t nz7 = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;  // bit 7 <=> byte != 0
+        r.d[k] = (nz7 >> 7) ^ 0x01010101u;
+    }
+    return r;
+}
+// reward of cube j of a pack: +1.0f if done else -1.0f  (cube_env.py:99-104)
+__device__ __forceinline__ float reward_of(uint32_t done_dword, int byte) {
+    return __uint_as_float(0xBF800000u ^ (((done_dword >> (8 * byte)) & 1u) << 31));
+}
+
+// ------------------------------------------------------------------------- one-hot code
+// 72-entry byte LUT in 18 literal dwords, index = packed byte h (< 72): 8-entry v_perm per group,
+// then a select tree on bits 3..5 (and bit 6 when the hash can reach 64).
+template <class T, int V, bool CORNER>
+__device__ __forceinline__ Pk<V> lut72(Pk<V> h) {
+    constexpr bool BIT6 = CORNER;  // only the corner hash (max 65) can reach 64
+    const Pk<V> lo3 = h & 0x07070707u;
+    Pk<V> g[8];
+    sfor<8>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr uint32_t hi = CORNER ? T::ccode_dw[2 * j + 1] : T::ecode_dw[2 * j + 1];
+        constexpr uint32_t lo = CORNER ? T::ccode_dw[2 * j] : T::ecode_dw[2 * j];
+        if constexpr (hi == 0 && lo == 0) g[j] = splat<V>(0);
+        else g[j] = perm<V>(hi, lo, lo3);
+    });
+    const Pk<V> m3 = signmask(shl(h, 4)), m4 = signmask(shl(h, 3)), m5 = signmask(shl(h, 2));
+    const Pk<V> a0 = sel(m3, g[1], g[0]), a1 = sel(m3, g[3], g[2]), a2 = sel(m3, g[5], g[4]), a3 = sel(m3, g[7], g[6]);
+    const Pk<V> b0 = sel(m4, a1, a0), b1 = sel(m4, a3, a2);
+    Pk<V> r = sel(m5, b1, b0);
+    if constexpr (BIT6) {
+        constexpr uint32_t hi = CORNER ? T::ccode_dw[17] : T::ecode_dw[17];
+        constexpr uint32_t lo = CORNER ? T::ccode_dw[16] : T::ecode_dw[16];
+        const Pk<V> m6 = signmask(shl(h, 1));
+        if constexpr (hi == 0 && lo == 0) r = andn(r, m6);
+        else r = sel(m6, perm<V>(hi, lo, lo3), r);
+    }
+    return r;
+}
+
+template <class T, int V, int SLOT>
+__device__ __forceinline__ Pk<V> encode_slot(const Pk<V> (&s)[T::S]) {
+    if constexpr (SLOT < T::NC) {
+        // h = c0 + 2*c1 + 10*c2   (py333.py:167,225); max 65 -> bit 6 can be set
+        constexpr int i0 = T::cdef[SLOT][0], i1 = T::cdef[SLOT][1], i2 = T::cdef[SLOT][2];
+        const Pk<V> c0 = s[i0], c1 = s[i1], c2 = s[i2];
+        const Pk<V> h = shl_add(c2, 1, shl_add(c2, 3, shl_add(c1, 1, c0)));
+        return lut72<T, V, true>(h);
+    } else {
+        // h = c0 + 10*c1          (py333.py:168,226); max 55
+        constexpr int e = SLOT - T::NC;
+        constexpr int i0 = T::edef[e][0], i1 = T::edef[e][1];
+        const Pk<V> c0 = s[i0], c1 = s[i1];
+        const Pk<V> h = shl_add(c1, 1, shl_add(c1, 3, c0));
+        return lut72<T, V, false>(h);
+    }
+}
+
+template <class T, int V>
+__device__ __forceinline__ void encode(const Pk<V> (&s)[T::S], Pk<V> (&code)[T::SLOTS]) {
+    sfor<T::SLOTS>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        code[p] = encode_slot<T, V, p>(s);
+    });
+}
+
+// code of the child by fixed action A_: untouched slots keep the parent's code
+template <class T, int V, int A_>
+__device__ __forceinline__ void encode_child(const Pk<V> (&child)[T::S], const Pk<V> (&pcode)[T::SLOTS], Pk<V> (&code)[T::SLOTS]) {
+    sfor<T::SLOTS>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        if constexpr (slot_moves<T>(A_, p)) code[p] = encode_slot<T, V, p>(child);
+        else code[p] = pcode[p];
+    });
+}
+
+// ------------------------------------------------------- dense one-hot from an LDS code tile
+// lds_code: [SLOTS][tp] bytes (tp = padded tile width), `ncubes` valid cubes, output element
+// type E in {uint8_t, uint16_t (IEEE half bits), float}; out points at the tile's first cube.
+template <class E> struct One;
+template <> struct One<uint8_t> { static constexpr uint32_t v = 1u; };
+template <> struct One<uint16_t> { static constexpr uint32_t v = 0x3C00u; };
+template <> struct One<float> { static constexpr uint32_t v = 0x3F800000u; };
+
+template <int BYTES> struct UIntOf;
+template <> struct UIntOf<1> { using type = uint8_t; };
+template <> struct UIntOf<2> { using type = uint16_t; };
+template <> struct UIntOf<4> { using type = uint32_t; };
+
+template <class T>
+__device__ __forceinline__ bool onehot_bit(const uint8_t *lds_code, int tp, uint32_t e) {
+    constexpr uint32_t RC = T::R * T::C;
+    const uint32_t cube = e / RC, w = e - cube * RC;
+    const uint32_t r = w / T::C, c = w - r * T::C;
+    if constexpr (T::SIZE == 3) {
+        return lds_code[r * tp + cube] == c;                    // row = slot, column = code
+    } else {
+        const uint32_t slot = c / 3, o = c - slot * 3;          // row = piece, column = slot*3+ori
+        return lds_code[slot * tp + cube] == r * 3 + o;
+    }
+}
+
+// flags of the 4 consecutive elements e..e+3 (e % 4 == 0), bit j = element e+j
+template <class T>
+__device__ __forceinline__ uint32_t onehot_bits4(const uint8_t *lds_code, int tp, uint32_t e, uint32_t total) {
+    if constexpr (T::SIZE == 3) {
+        // 24 % 4 == 0: the four elements share one row
+        const uint32_t cube = e / 480u, w = e - cube * 480u;
+        const uint32_t r = w / 24u, c0 = w - r * 24u;
+        const uint32_t d = (uint32_t)lds_code[r * tp + cube] - c0;
+        return d < 4u ? (1u << d) : 0u;
+    } else {
+        uint32_t b = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (e + j < total && onehot_bit<T>(lds_code, tp, e + j)) b |= 1u << j;
+        return b;
+    }
+}
+
+template <class T, class E>
+__device__ __forceinline__ void dense_write(const uint8_t *lds_code, int tp, E *out, int ncubes, int tid, int nthreads) {
+    constexpr int EPT = 16 / (int)sizeof(E);  // elements per 16-byte store
+    const uint32_t total = (uint32_t)ncubes * T::R * T::C;
+    const uint32_t chunks = (total + EPT - 1) / EPT;
+    for (uint32_t ch = tid; ch < chunks; ch += nthreads) {
+        const uint32_t e0 = ch * EPT;
+        uint32_t w[4];
+        if constexpr (sizeof(E) == 4) {
+            const uint32_t b = onehot_bits4<T>(lds_code, tp, e0, total);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = (b >> j & 1u) ? One<E>::v : 0u;
+        } else if constexpr (sizeof(E) == 2) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const uint32_t b = onehot_bits4<T>(lds_code, tp, e0 + 4 * g, total);
+                w[2 * g] = ((b & 1u) ? One<E>::v : 0u) | ((b & 2u) ? One<E>::v << 16 : 0u);
+                w[2 * g + 1] = ((b & 4u) ? One<E>::v : 0u) | ((b & 8u) ? One<E>::v << 16 : 0u);
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint32_t b = onehot_bits4<T>(lds_code, tp, e0 + 4 * g, total);
+                w[g] = (b & 1u) | ((b & 2u) << 7) | ((b & 4u) << 14) | ((b & 8u) << 21);
+            }
+        }
+        if (e0 + EPT <= total) {
+            u32x4 u = {w[0], w[1], w[2], w[3]};
+            __builtin_nontemporal_store(u, reinterpret_cast<u32x4 *>(out + e0));
+        } else {  // ragged end (2x2x2 only: 147 elements per cube)
+            for (uint32_t j = 0; e0 + j < total; ++j) {
+                const uint32_t bit = j * (uint32_t)sizeof(E) * 8u;   // element j inside the 128-bit chunk
+                out[e0 + j] = __builtin_bit_cast(E, (typename UIntOf<sizeof(E)>::type)(w[bit >> 5] >> (bit & 31u)));
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------- ADI RNG
+// DESIGN.md "RNG": per-walk xoroshiro128+ (24,16,37) seeded through splitmix64 from
+// (seed, stream_id, walk); action = (high 32 bits of the output * A) >> 32.
+__device__ __forceinline__ uint64_t sm64_next(uint64_t &st) {
+    uint64_t z = (st += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+struct WalkRng {
+    uint64_t s0, s1;
+    __device__ __forceinline__ void seed(uint64_t sd, uint64_t stream, uint64_t walk) {
+        uint64_t st = sd;
+        const uint64_t a = sm64_next(st);
+        st = a ^ stream;
+        const uint64_t b = sm64_next(st);
+        st = b ^ walk;
+        s0 = sm64_next(st);
+        s1 = sm64_next(st);
+        if ((s0 | s1) == 0) s1 = 0x9E3779B97F4A7C15ull;
+    }
+    __device__ __forceinline__ uint32_t action(uint32_t A) {
+        const uint64_t r = s0 + s1;
+        uint64_t t = s1 ^ s0;
+        s0 = ((s0 << 24) | (s0 >> 40)) ^ t ^ (t << 16);
+        s1 = (t << 37) | (t >> 27);
+        return __umulhi((uint32_t)(r >> 32), A);
+    }
+};
+
+}  // namespace rc

@@ -1,0 +1,686 @@
+// rubikhip.hip -- kernels and C ABI of librubikhip.so (see include/rubikhip.h).
+// gfx950 (MI355X, CDNA4) only; no other back end, no compatibility layer.
+//
+// Kernel map (DESIGN.md has the roofline of each):
+//   k_fill_solved     initState_3                      py333.py:211-218
+//   k_step            CubeEnv.step for N cubes          cube_env.py:71-111
+//                     (move + solved/reward + compact code, all in registers)
+//   k_step_dense      same + dense one-hot, the [slot][cube] code tile staged in LDS so the
+//                     [N][R][C] rows leave as coalesced 16-byte stores
+//   k_code_to_dense   compact code -> dense one-hot (same LDS stage)
+//   k_scramble        reset()'s scramble loop, in place    cube_env.py:65-67
+//   k_expand          12 children of every cube         cube_env.py:212-236, mcts.py:96-101
+//   k_adi             ADI walks + expansion, persistent over depth, per-walk xoroshiro128+
+//                                                       cube_env.py:177-194,212-236
+//   k_adi_targets     target value/policy/error         cube_env.py:229-232,239-251
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "../../include/rubikhip.h"
+#include "rc_device.h"
+
+using namespace rc;
+
+namespace {
+
+constexpr int kWave = 64;
+__device__ uint32_t g_status;  // RC_STATUS_* bits, per device (one code object instance per device)
+
+// ------------------------------------------------------------------------------ fill
+template <class T>
+__global__ void __launch_bounds__(256) k_fill_solved(uint8_t *base, int64_t n, int64_t pitch) {
+    const int64_t n0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (n0 >= n) return;
+#pragma unroll
+    for (int s = 0; s < T::S; ++s) st<4, false>(base + s * pitch + n0, splat<4>((uint32_t)(s / T::FACE) * 0x01010101u));
+}
+
+// ------------------------------------------------------------------------------ step
+struct StepArgs {
+    const uint8_t *in;
+    uint8_t *out;
+    const uint8_t *actions;
+    int64_t n, pitch_in, pitch_out;
+    float *reward;
+    uint8_t *done;
+    uint8_t *code;
+    int64_t code_pitch;
+};
+
+template <int V>
+__device__ __forceinline__ void store_reward(float *reward, int64_t n0, int64_t n, Pk<V> dn) {
+    if (n0 + 4 * V <= n) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float4 f = make_float4(reward_of(dn.d[k], 0), reward_of(dn.d[k], 1), reward_of(dn.d[k], 2), reward_of(dn.d[k], 3));
+            *reinterpret_cast<float4 *>(reward + n0 + 4 * k) = f;
+        }
+    } else {
+        for (int j = 0; j < 4 * V && n0 + j < n; ++j) reward[n0 + j] = reward_of(dn.d[j >> 2], j & 3);
+    }
+}
+
+// One lane = 4*V consecutive cubes.  MOVE: apply actions; STORE: write the state rows;
+// CODE: write the compact code rows; NT: non-temporal row traffic.
+template <class T, int V, bool MOVE, bool STORE, bool CODE, bool NT, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_step(StepArgs a) {
+    // wave-uniform part of the cube index in SGPRs, 32-bit lane offset in one VGPR
+    const int64_t g0 = (int64_t)blockIdx.x * (BLOCK * 4 * V);
+    const uint32_t lo = threadIdx.x * (4 * V);
+    const int64_t n0 = g0 + lo;
+    if (n0 >= a.n) return;
+    Pk<V> s[T::S];
+    {
+        const uint8_t *row = a.in + g0;
+#pragma unroll
+        for (int i = 0; i < T::S; ++i) { s[i] = ld<V, NT>(row + lo); row += a.pitch_in; }
+    }
+    if constexpr (MOVE) {
+        const Pk<V> act = ld_tail<V>(a.actions, n0, a.n, 0);
+        Pk<V> m[T::A];
+        const Pk<V> bad = action_masks<T, V>(act, m);
+        if (any(bad)) atomicOr(&g_status, RC_STATUS_BAD_ACTION);
+        Pk<V> o[T::S];
+        apply_move<T, V>(s, m, o);
+#pragma unroll
+        for (int i = 0; i < T::S; ++i) s[i] = o[i];
+    }
+    if constexpr (STORE) {
+        uint8_t *row = a.out + g0;
+#pragma unroll
+        for (int i = 0; i < T::S; ++i) { st<V, NT>(row + lo, s[i]); row += a.pitch_out; }
+    }
+    if (a.done != nullptr || a.reward != nullptr) {
+        const Pk<V> dn = done_bytes(unsolved<T, V>(s));
+        if (a.done) st_tail<V>(a.done, n0, a.n, dn);
+        if (a.reward) store_reward<V>(a.reward, n0, a.n, dn);
+    }
+    if constexpr (CODE) {
+        Pk<V> c[T::SLOTS];
+        encode<T, V>(s, c);
+        uint8_t *row = a.code + g0;
+#pragma unroll
+        for (int p = 0; p < T::SLOTS; ++p) { st<V, NT>(row + lo, c[p]); row += a.code_pitch; }
+    }
+}
+
+// ----------------------------------------------------------- step + dense one-hot (LDS stage)
+constexpr int kDenseBlock = 256;
+constexpr int kDenseTile = kDenseBlock * 4;  // cubes per workgroup
+constexpr int kDenseTp = kDenseTile + 4;     // LDS row pitch in bytes: 257 dwords -> rows fall on different banks
+
+template <class T, class E, bool MOVE, bool STORE>
+__global__ void __launch_bounds__(kDenseBlock) k_step_dense(StepArgs a, E *dense) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds_code[T::SLOTS * kDenseTp];
+    const int64_t tile0 = (int64_t)blockIdx.x * kDenseTile;
+    const uint32_t lo = threadIdx.x * 4;
+    const int64_t n0 = tile0 + lo;
+    if (n0 < a.n) {
+        Pk<1> s[T::S];
+        {
+            const uint8_t *row = a.in + tile0;
+#pragma unroll
+            for (int i = 0; i < T::S; ++i) { s[i] = ld<1, false>(row + lo); row += a.pitch_in; }
+        }
+        if constexpr (MOVE) {
+            const Pk<1> act = ld_tail<1>(a.actions, n0, a.n, 0);
+            Pk<1> m[T::A];
+            const Pk<1> bad = action_masks<T, 1>(act, m);
+            if (any(bad)) atomicOr(&g_status, RC_STATUS_BAD_ACTION);
+            Pk<1> o[T::S];
+            apply_move<T, 1>(s, m, o);
+#pragma unroll
+            for (int i = 0; i < T::S; ++i) s[i] = o[i];
+        }
+        if constexpr (STORE) {
+            uint8_t *row = a.out + tile0;
+#pragma unroll
+            for (int i = 0; i < T::S; ++i) { st<1, false>(row + lo, s[i]); row += a.pitch_out; }
+        }
+        if (a.done != nullptr || a.reward != nullptr) {
+            const Pk<1> dn = done_bytes(unsolved<T, 1>(s));
+            if (a.done) st_tail<1>(a.done, n0, a.n, dn);
+            if (a.reward) store_reward<1>(a.reward, n0, a.n, dn);
+        }
+        Pk<1> c[T::SLOTS];
+        encode<T, 1>(s, c);
+#pragma unroll
+        for (int p = 0; p < T::SLOTS; ++p) *reinterpret_cast<uint32_t *>(lds_code + p * kDenseTp + threadIdx.x * 4) = c[p].d[0];
+    }
+    __syncthreads();
+    const int64_t left = a.n - tile0;
+    const int ncubes = left < kDenseTile ? (int)left : kDenseTile;
+    dense_write<T, E>(lds_code, kDenseTp, dense + tile0 * (T::R * T::C), ncubes, threadIdx.x, kDenseBlock);
+}
+
+template <class T, class E>
+__global__ void __launch_bounds__(kDenseBlock) k_code_to_dense(const uint8_t *code, int64_t n, int64_t code_pitch, E *dense) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds_code[T::SLOTS * kDenseTp];
+    const int64_t tile0 = (int64_t)blockIdx.x * kDenseTile;
+    const int64_t n0 = tile0 + threadIdx.x * 4;
+    if (n0 < n) {
+#pragma unroll
+        for (int p = 0; p < T::SLOTS; ++p)
+            *reinterpret_cast<uint32_t *>(lds_code + p * kDenseTp + threadIdx.x * 4) = ld<1, false>(code + p * code_pitch + n0).d[0];
+    }
+    __syncthreads();
+    const int64_t left = n - tile0;
+    const int ncubes = left < kDenseTile ? (int)left : kDenseTile;
+    dense_write<T, E>(lds_code, kDenseTp, dense + tile0 * (T::R * T::C), ncubes, threadIdx.x, kDenseBlock);
+}
+
+// ---------------------------------------------------------------------------- expand
+struct ExpandArgs {
+    const uint8_t *in;
+    int64_t n, pitch_in;
+    uint8_t *children, *child_solved, *child_code;
+    int64_t pitch_out;
+    int parts;
+};
+
+// Row addressing: every row pointer handed to these helpers is WAVE-UNIFORM (kernel argument +
+// block-derived offset, lives in SGPRs); the lane adds a 32-bit offset `lo`.  Keeps the 648
+// child-row addresses of one expansion out of the vector registers.
+__device__ __forceinline__ uint8_t *opaque(uint8_t *p) {
+    // defined inside the loop body on purpose: stops the optimiser from turning every row of
+    // every child into its own loop-carried address register
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+template <class T, int V, int A_, bool CODE>
+__device__ __forceinline__ void emit_child(const Pk<V> (&s)[T::S], const Pk<V> (&pcode)[T::SLOTS],
+                                           uint8_t *children, uint8_t *child_solved, uint8_t *child_code, int64_t pitch, uint32_t lo) {
+    Pk<V> c[T::S];
+    fixed_move<T, V, A_>(s, c);
+    if (children) {
+        uint8_t *row = opaque(children + (int64_t)A_ * T::S * pitch);
+#pragma unroll
+        for (int i = 0; i < T::S; ++i) { st<V, true>(row + lo, c[i]); row += pitch; }
+    }
+    if (child_solved) st<V, true>(child_solved + (int64_t)A_ * pitch + lo, done_bytes(unsolved<T, V>(c)));
+    if constexpr (CODE) {
+        Pk<V> cc[T::SLOTS];
+        encode_child<T, V, A_>(c, pcode, cc);
+        uint8_t *row = opaque(child_code + (int64_t)A_ * T::SLOTS * pitch);
+#pragma unroll
+        for (int p = 0; p < T::SLOTS; ++p) { st<V, true>(row + lo, cc[p]); row += pitch; }
+    }
+}
+
+// children part, part+parts, ... of one parent pack; pointers are wave-uniform
+template <class T, int V, bool CODE>
+__device__ __forceinline__ void emit_children(const Pk<V> (&s)[T::S], int part, int parts,
+                                              uint8_t *children, uint8_t *child_solved, uint8_t *child_code, int64_t pitch, uint32_t lo) {
+    Pk<V> pcode[T::SLOTS];
+    if constexpr (CODE) encode<T, V>(s, pcode);
+    sfor<T::A>([&](auto ac) {
+        constexpr int a = decltype(ac)::value;
+        if ((a - part) % parts == 0 && a >= part)
+            emit_child<T, V, a, CODE>(s, pcode, children, child_solved, child_code, pitch, lo);
+    });
+}
+
+template <class T, int V, bool CODE>
+__global__ void __launch_bounds__(kWave) k_expand(ExpandArgs a) {
+    const int64_t item = blockIdx.x;
+    const int64_t g = item / a.parts;
+    const int part = (int)(item - g * a.parts);
+    const int64_t g0 = g * (kWave * 4 * V);
+    const uint32_t lo = threadIdx.x * (4 * V);
+    if (g0 + lo >= a.n) return;
+    Pk<V> s[T::S];
+    {
+        const uint8_t *row = a.in + g0;
+#pragma unroll
+        for (int i = 0; i < T::S; ++i) { s[i] = ld<V, false>(row + lo); row += a.pitch_in; }
+    }
+    emit_children<T, V, CODE>(s, part, a.parts, a.children ? a.children + g0 : nullptr, a.child_solved ? a.child_solved + g0 : nullptr,
+                              a.child_code ? a.child_code + g0 : nullptr, a.pitch_out, lo);
+}
+
+// ------------------------------------------------------------------------------- ADI
+struct AdiArgs {
+    uint64_t seed, stream_id;
+    int64_t walk_offset, n_walks, pitch;
+    int depth, parts;
+    const uint8_t *actions_in;
+    uint8_t *actions_out, *parents, *parent_code, *children, *child_code, *child_solved;
+};
+
+// One wave = 256*V walks, kept in registers for all `depth` steps (persistent over depth).
+// `parts` waves share a walk group: each recomputes the (cheap) walk and writes its share of
+// the children, which is where all the bytes go; part 0 also writes actions and parents.
+template <class T, int V, bool CODE>
+__global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
+    const int64_t item = blockIdx.x;
+    const int64_t g = item / a.parts;
+    const int part = (int)(item - g * a.parts);
+    const int64_t g0 = g * (kWave * 4 * V);
+    const uint32_t lo = threadIdx.x * (4 * V);
+    const int64_t w0 = g0 + lo;
+    if (w0 >= a.n_walks) return;
+    Pk<V> s[T::S];
+#pragma unroll
+    for (int i = 0; i < T::S; ++i) s[i] = splat<V>((uint32_t)(i / T::FACE) * 0x01010101u);
+    WalkRng rng[4 * V];
+    if (a.actions_in == nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4 * V; ++j) rng[j].seed(a.seed, a.stream_id, (uint64_t)(a.walk_offset + w0 + j));
+    }
+    for (int d = 0; d < a.depth; ++d) {
+        Pk<V> act;
+        if (a.actions_in != nullptr) {
+            act = ld<V, false>(a.actions_in + (int64_t)d * a.pitch + w0);
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                uint32_t x = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x |= rng[4 * k + j].action(T::A) << (8 * j);
+                act.d[k] = x;
+            }
+        }
+        Pk<V> m[T::A];
+        const Pk<V> bad = action_masks<T, V>(act, m);
+        if (any(bad)) atomicOr(&g_status, RC_STATUS_BAD_ACTION);
+        Pk<V> o[T::S];
+        apply_move<T, V>(s, m, o);
+#pragma unroll
+        for (int i = 0; i < T::S; ++i) s[i] = o[i];
+        if (part == 0) {
+            if (a.actions_out) st<V, true>(a.actions_out + (int64_t)d * a.pitch + w0, act);
+            if (a.parents) {
+                uint8_t *row = opaque(a.parents + (int64_t)d * T::S * a.pitch + g0);
+#pragma unroll
+                for (int i = 0; i < T::S; ++i) { st<V, true>(row + lo, s[i]); row += a.pitch; }
+            }
+            if constexpr (CODE) {
+                if (a.parent_code) {
+                    Pk<V> pc[T::SLOTS];
+                    encode<T, V>(s, pc);
+                    uint8_t *row = opaque(a.parent_code + (int64_t)d * T::SLOTS * a.pitch + g0);
+#pragma unroll
+                    for (int p = 0; p < T::SLOTS; ++p) { st<V, true>(row + lo, pc[p]); row += a.pitch; }
+                }
+            }
+        }
+        uint8_t *ch = a.children ? a.children + (int64_t)d * T::A * T::S * a.pitch + g0 : nullptr;
+        uint8_t *cs = a.child_solved ? a.child_solved + (int64_t)d * T::A * a.pitch + g0 : nullptr;
+        uint8_t *cc = a.child_code ? a.child_code + (int64_t)d * T::A * T::SLOTS * a.pitch + g0 : nullptr;
+        if (CODE && cc != nullptr) emit_children<T, V, CODE>(s, part, a.parts, ch, cs, cc, a.pitch, lo);
+        else emit_children<T, V, false>(s, part, a.parts, ch, cs, nullptr, a.pitch, lo);
+    }
+}
+
+// -------------------------------------------------------------------------- scramble
+struct ScrambleArgs {
+    uint8_t *st;
+    int64_t n, pitch;
+    int depth;
+    uint64_t seed, stream_id;
+    int64_t walk_offset;
+    const uint8_t *actions_in;
+    uint8_t *actions_out;
+    int64_t act_pitch;
+    uint8_t *done;
+    float *reward;
+};
+
+template <class T>
+__global__ void __launch_bounds__(kWave) k_scramble(ScrambleArgs a) {
+    constexpr int V = 1;
+    const int64_t g0 = (int64_t)blockIdx.x * (kWave * 4 * V);
+    const uint32_t lo = threadIdx.x * (4 * V);
+    const int64_t n0 = g0 + lo;
+    if (n0 >= a.n) return;
+    Pk<V> s[T::S];
+    {
+        const uint8_t *row = a.st + g0;
+#pragma unroll
+        for (int i = 0; i < T::S; ++i) { s[i] = ld<V, false>(row + lo); row += a.pitch; }
+    }
+    WalkRng rng[4 * V];
+    if (a.actions_in == nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4 * V; ++j) rng[j].seed(a.seed, a.stream_id, (uint64_t)(a.walk_offset + n0 + j));
+    }
+    for (int d = 0; d < a.depth; ++d) {
+        Pk<V> act;
+        if (a.actions_in != nullptr) {
+            act = ld<V, false>(a.actions_in + (int64_t)d * a.act_pitch + n0);
+        } else {
+            uint32_t x = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x |= rng[j].action(T::A) << (8 * j);
+            act.d[0] = x;
+        }
+        if (a.actions_out) st<V, false>(a.actions_out + (int64_t)d * a.act_pitch + n0, act);
+        Pk<V> m[T::A];
+        const Pk<V> bad = action_masks<T, V>(act, m);
+        if (any(bad)) atomicOr(&g_status, RC_STATUS_BAD_ACTION);
+        Pk<V> o[T::S];
+        apply_move<T, V>(s, m, o);
+#pragma unroll
+        for (int i = 0; i < T::S; ++i) s[i] = o[i];
+    }
+    {
+        uint8_t *row = a.st + g0;
+#pragma unroll
+        for (int i = 0; i < T::S; ++i) { st<V, false>(row + lo, s[i]); row += a.pitch; }
+    }
+    if (a.done != nullptr || a.reward != nullptr) {
+        const Pk<V> dn = done_bytes(unsolved<T, V>(s));
+        if (a.done) st_tail<V>(a.done, n0, a.n, dn);
+        if (a.reward) store_reward<V>(a.reward, n0, a.n, dn);
+    }
+}
+
+// ------------------------------------------------------------------------ ADI targets
+template <int A_>
+__global__ void __launch_bounds__(256) k_adi_targets(const float *child_value, const uint8_t *child_solved, const float *parent_value,
+                                                     const double *weight, int64_t n, int64_t pitch,
+                                                     float *target_value, int32_t *target_policy, double *error) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float best = 0.f;
+    int arg = -1, solved_at = -1;
+#pragma unroll
+    for (int k = 0; k < A_; ++k) {
+        const float v = child_value[k * pitch + i] + (-1.0f);       // cube_env.py:244  value + reward
+        if (child_solved[k * pitch + i] && solved_at < 0) solved_at = k;  // cube_env.py:229-232  first solved child wins
+        if (arg < 0 || v > best) { best = v; arg = k; }               // torch.max: first maximal index
+    }
+    const float tv = solved_at >= 0 ? 1.0f : best;
+    target_value[i] = tv;
+    target_policy[i] = solved_at >= 0 ? solved_at : arg;
+    if (error) error[i] = fabs((double)parent_value[i] - (double)tv) * weight[i];  // cube_env.py:247-251
+}
+
+// ------------------------------------------------------------------------- host side
+thread_local char t_err[256] = "";
+int g_variant = 0;
+
+int fail(int code, const char *fmt, const char *detail = "") {
+    snprintf(t_err, sizeof t_err, fmt, detail);
+    return code;
+}
+#define RC_HIP(call)                                                              \
+    do {                                                                          \
+        hipError_t e_ = (call);                                                   \
+        if (e_ != hipSuccess) return fail(RC_EHIP, #call ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline bool bad_pitch(int64_t pitch, int64_t n) { return pitch < n || (pitch & 15) != 0; }
+inline hipStream_t S(void *s) { return static_cast<hipStream_t>(s); }
+
+template <class F>
+int by_size(int cube_size, F &&f) {
+    if (cube_size == 3) return f(Cube3{});
+    if (cube_size == 2) return f(Cube2{});
+    return fail(RC_EINVAL, "cube_size must be 2 or 3%s");  // NotImplementedError, cube_env.py:44
+}
+
+// pack width: widest vector that still gives the chip enough waves
+int pick_v(int64_t n) {
+    if (g_variant >= 1 && g_variant <= 3) return g_variant == 1 ? 1 : g_variant == 2 ? 2 : 4;
+    if (n >= (int64_t)1 << 21) return 4;
+    if (n >= (int64_t)1 << 19) return 2;
+    return 1;
+}
+
+template <class T, int V, bool MOVE, bool STORE, bool CODE>
+int launch_step(const StepArgs &a, hipStream_t st) {
+    constexpr int BLOCK = 64;
+    const int64_t lanes = (a.n + 4 * V - 1) / (4 * V);
+    const int64_t blocks = (lanes + BLOCK - 1) / BLOCK;
+    if (blocks > 0x7fffffff) return fail(RC_EINVAL, "too many cubes for one launch%s");
+    const bool nt = g_variant >= 10;
+    if (nt) hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, true, BLOCK>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
+    else hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, false, BLOCK>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
+template <class T, bool MOVE, bool STORE, bool CODE>
+int dispatch_step(const StepArgs &a, hipStream_t st) {
+    switch (pick_v(a.n)) {
+        case 4: return launch_step<T, 4, MOVE, STORE, CODE>(a, st);
+        case 2: return launch_step<T, 2, MOVE, STORE, CODE>(a, st);
+        default: return launch_step<T, 1, MOVE, STORE, CODE>(a, st);
+    }
+}
+
+template <class T, bool MOVE, bool STORE>
+int launch_dense(const StepArgs &a, void *onehot, int fmt, hipStream_t st) {
+    const int64_t blocks = (a.n + kDenseTile - 1) / kDenseTile;
+    if (blocks > 0x7fffffff) return fail(RC_EINVAL, "too many cubes for one launch%s");
+    const dim3 g((unsigned)blocks), b(kDenseBlock);
+    if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_step_dense<T, uint8_t, MOVE, STORE>), g, b, 0, st, a, static_cast<uint8_t *>(onehot));
+    else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_step_dense<T, uint16_t, MOVE, STORE>), g, b, 0, st, a, static_cast<uint16_t *>(onehot));
+    else hipLaunchKernelGGL((k_step_dense<T, float, MOVE, STORE>), g, b, 0, st, a, static_cast<float *>(onehot));
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
+int check_fmt(void *onehot, int fmt, int64_t code_pitch, int64_t n) {
+    if (fmt < RC_FMT_NONE || fmt > RC_FMT_F32) return fail(RC_EINVAL, "unknown one-hot format%s");
+    if ((fmt == RC_FMT_NONE) != (onehot == nullptr)) return fail(RC_EINVAL, "onehot pointer and fmt disagree%s");
+    if (onehot && !aligned16(onehot)) return fail(RC_EINVAL, "onehot must be 16-byte aligned%s");
+    if (fmt == RC_FMT_CODE && bad_pitch(code_pitch, n)) return fail(RC_EINVAL, "code_pitch must be >= n_cubes and a multiple of 16%s");
+    return RC_OK;
+}
+
+int parts_for(int64_t groups, int A) {
+    // enough wave-items to cover 256 CUs a few times over; parts must divide the work evenly enough
+    const int64_t want = 2048;
+    int parts = 1;
+    while (parts < A && groups * parts < want) ++parts;
+    while (A % parts) ++parts;  // 1,2,3,4,6,12 | 1,2,3,6
+    return parts;
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+int rc_version(void) { return 100; }
+
+const char *rc_last_error(void) { return t_err; }
+
+int rc_set_variant(int variant) {
+    g_variant = variant;
+    return RC_OK;
+}
+
+int rc_init(int device) {
+    int count = 0;
+    RC_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(RC_ENODEV, "no such HIP device%s");
+    RC_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    RC_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(RC_ENODEV, "librubikhip is built for gfx950 only, device is %s", prop.gcnArchName);
+    uint32_t zero = 0;
+    RC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_status), &zero, sizeof zero));
+    return RC_OK;
+}
+
+int rc_get_tables(int cube_size, uint8_t *perm, uint8_t *solved, uint8_t *corner_defs, uint8_t *edge_defs,
+                  uint8_t *corner_code, uint8_t *edge_code, int32_t dims[6]) {
+    return by_size(cube_size, [&](auto t) {
+        using T = decltype(t);
+        if (perm) memcpy(perm, kPerm<T>.v, sizeof kPerm<T>.v);
+        if (solved) for (int i = 0; i < T::S; ++i) solved[i] = (uint8_t)(i / T::FACE);
+        if (corner_defs) memcpy(corner_defs, T::cdef, (size_t)T::NC * 3);
+        if (edge_defs && T::NE) memcpy(edge_defs, T::edef, (size_t)T::NE * 2);
+        if (corner_code) memcpy(corner_code, T::ccode, 72);
+        if (edge_code) memcpy(edge_code, T::ecode, 72);
+        if (dims) { dims[0] = T::S; dims[1] = T::A; dims[2] = T::NC; dims[3] = T::NE; dims[4] = T::R; dims[5] = T::C; }
+        return RC_OK;
+    });
+}
+
+int rc_fill_solved(uint8_t *stp, int64_t n, int64_t pitch, int cube_size, void *stream) {
+    if (!stp || !aligned16(stp) || n < 0 || bad_pitch(pitch, n)) return fail(RC_EINVAL, "rc_fill_solved: bad buffer / pitch%s");
+    if (n == 0) return RC_OK;
+    return by_size(cube_size, [&](auto t) {
+        using T = decltype(t);
+        const int64_t blocks = ((n + 15) / 16 + 255) / 256;
+        hipLaunchKernelGGL((k_fill_solved<T>), dim3((unsigned)blocks), dim3(256), 0, S(stream), stp, n, pitch);
+        RC_HIP(hipGetLastError());
+        return RC_OK;
+    });
+}
+
+static int step_common(const uint8_t *in, uint8_t *out, const uint8_t *actions, int64_t n, int64_t pitch_in, int64_t pitch_out,
+                       int cube_size, float *reward, uint8_t *done, void *onehot, int fmt, int64_t code_pitch, void *stream,
+                       bool move, bool store) {
+    if (!in || !aligned16(in) || n < 0 || bad_pitch(pitch_in, n)) return fail(RC_EINVAL, "bad input state buffer / pitch%s");
+    if (store && (!out || !aligned16(out) || bad_pitch(pitch_out, n))) return fail(RC_EINVAL, "bad output state buffer / pitch%s");
+    if (move && !actions) return fail(RC_EINVAL, "actions is NULL%s");
+    if (reward && (reinterpret_cast<uintptr_t>(reward) & 15u)) return fail(RC_EINVAL, "reward must be 16-byte aligned%s");
+    if (int rc = check_fmt(onehot, fmt, code_pitch, n)) return rc;
+    if (n == 0) return RC_OK;
+    StepArgs a{in, out, actions, n, pitch_in, pitch_out, reward, done, fmt == RC_FMT_CODE ? static_cast<uint8_t *>(onehot) : nullptr, code_pitch};
+    hipStream_t st = S(stream);
+    return by_size(cube_size, [&](auto t) {
+        using T = decltype(t);
+        if (fmt >= RC_FMT_U8) {
+            if (move) return launch_dense<T, true, true>(a, onehot, fmt, st);
+            return launch_dense<T, false, false>(a, onehot, fmt, st);
+        }
+        if (move) {
+            if (fmt == RC_FMT_CODE) return dispatch_step<T, true, true, true>(a, st);
+            return dispatch_step<T, true, true, false>(a, st);
+        }
+        if (fmt == RC_FMT_CODE) return dispatch_step<T, false, false, true>(a, st);
+        return dispatch_step<T, false, false, false>(a, st);
+    });
+}
+
+int rc_apply_moves(const uint8_t *in, uint8_t *out, const uint8_t *actions, int64_t n, int64_t pitch_in, int64_t pitch_out,
+                   int cube_size, float *reward, uint8_t *done, void *onehot, int fmt, int64_t code_pitch, void *stream) {
+    return step_common(in, out, actions, n, pitch_in, pitch_out, cube_size, reward, done, onehot, fmt, code_pitch, stream, true, true);
+}
+
+int rc_scramble(uint8_t *stp, int64_t n, int64_t pitch, int cube_size, int depth, uint64_t seed, uint64_t stream_id,
+                int64_t walk_offset, const uint8_t *actions_in, uint8_t *actions_out, int64_t act_pitch, uint8_t *done,
+                float *reward, void *stream) {
+    if (!stp || !aligned16(stp) || n < 0 || depth < 0 || bad_pitch(pitch, n)) return fail(RC_EINVAL, "rc_scramble: bad state buffer / pitch%s");
+    if ((actions_in || actions_out) && bad_pitch(act_pitch, n)) return fail(RC_EINVAL, "rc_scramble: bad act_pitch%s");
+    if ((actions_in && !aligned16(actions_in)) || (actions_out && !aligned16(actions_out))) return fail(RC_EINVAL, "rc_scramble: action buffers must be 16-byte aligned%s");
+    if (reward && (reinterpret_cast<uintptr_t>(reward) & 15u)) return fail(RC_EINVAL, "reward must be 16-byte aligned%s");
+    if (n == 0) return RC_OK;
+    return by_size(cube_size, [&](auto t) {
+        using T = decltype(t);
+        ScrambleArgs a{stp, n, pitch, depth, seed, stream_id, walk_offset, actions_in, actions_out, act_pitch, done, reward};
+        const dim3 g((unsigned)((n + kWave * 4 - 1) / (kWave * 4))), b(kWave);
+        hipLaunchKernelGGL((k_scramble<T>), g, b, 0, S(stream), a);
+        RC_HIP(hipGetLastError());
+        return RC_OK;
+    });
+}
+
+int rc_is_solved(const uint8_t *stp, int64_t n, int64_t pitch, int cube_size, uint8_t *done, float *reward, void *stream) {
+    if (!done && !reward) return fail(RC_EINVAL, "rc_is_solved: nothing to write%s");
+    return step_common(stp, nullptr, nullptr, n, pitch, 0, cube_size, reward, done, nullptr, RC_FMT_NONE, 0, stream, false, false);
+}
+
+int rc_encode(const uint8_t *stp, int64_t n, int64_t pitch, int cube_size, void *onehot, int fmt, int64_t code_pitch, void *stream) {
+    if (fmt == RC_FMT_NONE) return fail(RC_EINVAL, "rc_encode: fmt must not be RC_FMT_NONE%s");
+    return step_common(stp, nullptr, nullptr, n, pitch, 0, cube_size, nullptr, nullptr, onehot, fmt, code_pitch, stream, false, false);
+}
+
+int rc_onehot_from_code(const uint8_t *code, int64_t n, int64_t code_pitch, int cube_size, void *onehot, int fmt, void *stream) {
+    if (!code || !aligned16(code) || n < 0 || bad_pitch(code_pitch, n)) return fail(RC_EINVAL, "bad code buffer / pitch%s");
+    if (fmt < RC_FMT_U8 || fmt > RC_FMT_F32 || !onehot || !aligned16(onehot)) return fail(RC_EINVAL, "rc_onehot_from_code: dense fmt and aligned buffer required%s");
+    if (n == 0) return RC_OK;
+    return by_size(cube_size, [&](auto t) {
+        using T = decltype(t);
+        const dim3 g((unsigned)((n + kDenseTile - 1) / kDenseTile)), b(kDenseBlock);
+        if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_code_to_dense<T, uint8_t>), g, b, 0, S(stream), code, n, code_pitch, static_cast<uint8_t *>(onehot));
+        else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_code_to_dense<T, uint16_t>), g, b, 0, S(stream), code, n, code_pitch, static_cast<uint16_t *>(onehot));
+        else hipLaunchKernelGGL((k_code_to_dense<T, float>), g, b, 0, S(stream), code, n, code_pitch, static_cast<float *>(onehot));
+        RC_HIP(hipGetLastError());
+        return RC_OK;
+    });
+}
+
+int rc_expand_children(const uint8_t *in, int64_t n, int64_t pitch_in, int cube_size, uint8_t *children, uint8_t *child_solved,
+                       uint8_t *child_code, int64_t pitch_out, void *stream) {
+    if (!in || !aligned16(in) || n < 0 || bad_pitch(pitch_in, n) || bad_pitch(pitch_out, n)) return fail(RC_EINVAL, "rc_expand_children: bad buffer / pitch%s");
+    if (!children && !child_solved && !child_code) return fail(RC_EINVAL, "rc_expand_children: nothing to write%s");
+    if ((children && !aligned16(children)) || (child_solved && !aligned16(child_solved)) || (child_code && !aligned16(child_code)))
+        return fail(RC_EINVAL, "rc_expand_children: outputs must be 16-byte aligned%s");
+    if (n == 0) return RC_OK;
+    return by_size(cube_size, [&](auto t) {
+        using T = decltype(t);
+        const int V = n >= ((int64_t)1 << 20) ? 2 : 1;
+        const int64_t groups = (n + kWave * 4 * V - 1) / (kWave * 4 * V);
+        ExpandArgs a{in, n, pitch_in, children, child_solved, child_code, pitch_out, parts_for(groups, T::A)};
+        const dim3 g((unsigned)(groups * a.parts)), b(kWave);
+        hipStream_t st = S(stream);
+        if (V == 2) {
+            if (child_code) hipLaunchKernelGGL((k_expand<T, 2, true>), g, b, 0, st, a);
+            else hipLaunchKernelGGL((k_expand<T, 2, false>), g, b, 0, st, a);
+        } else {
+            if (child_code) hipLaunchKernelGGL((k_expand<T, 1, true>), g, b, 0, st, a);
+            else hipLaunchKernelGGL((k_expand<T, 1, false>), g, b, 0, st, a);
+        }
+        RC_HIP(hipGetLastError());
+        return RC_OK;
+    });
+}
+
+int rc_adi_generate(uint64_t seed, uint64_t stream_id, int64_t walk_offset, int64_t n_walks, int depth, int cube_size, int64_t pitch,
+                    const uint8_t *actions_in, uint8_t *actions_out, uint8_t *parents, uint8_t *parent_code, uint8_t *children,
+                    uint8_t *child_code, uint8_t *child_solved, void *stream) {
+    if (n_walks < 0 || depth < 0 || bad_pitch(pitch, n_walks)) return fail(RC_EINVAL, "rc_adi_generate: bad sizes / pitch%s");
+    const void *ptrs[] = {actions_in, actions_out, parents, parent_code, children, child_code, child_solved};
+    for (const void *p : ptrs)
+        if (p && !aligned16(p)) return fail(RC_EINVAL, "rc_adi_generate: buffers must be 16-byte aligned%s");
+    if (n_walks == 0 || depth == 0) return RC_OK;
+    return by_size(cube_size, [&](auto t) {
+        using T = decltype(t);
+        const int V = 1;
+        const int64_t groups = (n_walks + kWave * 4 * V - 1) / (kWave * 4 * V);
+        const bool any_child = children || child_code || child_solved;
+        AdiArgs a{seed, stream_id, walk_offset, n_walks, pitch, depth, any_child ? parts_for(groups, T::A) : 1,
+                  actions_in, actions_out, parents, parent_code, children, child_code, child_solved};
+        const dim3 g((unsigned)(groups * a.parts)), b(kWave);
+        if (parent_code || child_code) hipLaunchKernelGGL((k_adi<T, 1, true>), g, b, 0, S(stream), a);
+        else hipLaunchKernelGGL((k_adi<T, 1, false>), g, b, 0, S(stream), a);
+        RC_HIP(hipGetLastError());
+        return RC_OK;
+    });
+}
+
+int rc_adi_targets(const float *child_value, const uint8_t *child_solved, const float *parent_value, const double *weight, int64_t n,
+                   int64_t pitch, int cube_size, float *target_value, int32_t *target_policy, double *error, void *stream) {
+    if (!child_value || !child_solved || !target_value || !target_policy || n < 0 || pitch < n) return fail(RC_EINVAL, "rc_adi_targets: bad arguments%s");
+    if (error && (!parent_value || !weight)) return fail(RC_EINVAL, "rc_adi_targets: error needs parent_value and weight%s");
+    if (n == 0) return RC_OK;
+    const dim3 g((unsigned)((n + 255) / 256)), b(256);
+    if (cube_size == 3) hipLaunchKernelGGL((k_adi_targets<12>), g, b, 0, S(stream), child_value, child_solved, parent_value, weight, n, pitch, target_value, target_policy, error);
+    else if (cube_size == 2) hipLaunchKernelGGL((k_adi_targets<6>), g, b, 0, S(stream), child_value, child_solved, parent_value, weight, n, pitch, target_value, target_policy, error);
+    else return fail(RC_EINVAL, "cube_size must be 2 or 3%s");
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_read_status(uint32_t *status, void *stream) {
+    if (!status) return fail(RC_EINVAL, "status is NULL%s");
+    uint32_t zero = 0;
+    RC_HIP(hipStreamSynchronize(S(stream)));
+    RC_HIP(hipMemcpyFromSymbol(status, HIP_SYMBOL(g_status), sizeof *status));
+    if (*status) RC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_status), &zero, sizeof zero));
+    return RC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,189 @@
+"""Batched cube operators on PyTorch-ROCm tensors: the device analogue of the reference's
+operator layer (gym-cube/gym_cube/envs/assets/py333.py:211-246: initState_3, doMove_3,
+isSolved_3, getOP_3 + pos_to_state_3) plus the env loops built on it.  Each function
+validates its tensors and forwards raw pointers + the current HIP stream to librubikhip.so.
+
+State layout: uint8 tensor [S, pitch] (structure of arrays: one row per sticker, one column
+per cube), pitch a multiple of 256; only the first n columns are cubes.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import FMT_CODE, FMT_F16, FMT_F32, FMT_NONE, FMT_U8, RubikHipError, check, lib, ptr, stream_ptr
+from .tables import ACTION_DIM, STATE_DIM
+
+N_STICKERS = {2: 24, 3: 54}
+N_SLOTS = {2: 7, 3: 20}
+
+
+def _size(cube_size):
+    if cube_size not in (2, 3):
+        raise NotImplementedError(f"cube_size {cube_size}")  # cube_env.py:44,106,151
+    return N_STICKERS[cube_size], ACTION_DIM[cube_size], N_SLOTS[cube_size]
+
+
+def _rows(t, rows, n, what):
+    """t must be a contiguous uint8 device tensor [..., rows, pitch] with pitch >= n, pitch % 16 == 0."""
+    if t.dtype != torch.uint8 or not t.is_cuda or not t.is_contiguous():
+        raise RubikHipError(f"{what}: need a contiguous uint8 HIP tensor")
+    if t.dim() < 2 or t.shape[-2] != rows or t.shape[-1] < n or t.shape[-1] % 16:
+        raise RubikHipError(f"{what}: shape {tuple(t.shape)} is not [..., {rows}, pitch>=n, pitch%16==0]")
+    return t.shape[-1]
+
+
+def _vec(t, n, dtype, what):
+    if t is None:
+        return None
+    if t.dtype != dtype or not t.is_cuda or not t.is_contiguous() or t.numel() < n:
+        raise RubikHipError(f"{what}: need a contiguous {dtype} HIP tensor with >= {n} elements")
+    return t
+
+
+def alloc_states(n, cube_size, device, pitch=None):
+    S, _, _ = _size(cube_size)
+    pitch = pitch or _lib.pitch_for(n)
+    return torch.empty((S, pitch), dtype=torch.uint8, device=device)
+
+
+def fill_solved(st, n, cube_size):
+    S, _, _ = _size(cube_size)
+    pitch = _rows(st, S, n, "fill_solved")
+    _lib.init(st.device)
+    check(lib().rc_fill_solved(ptr(st), n, pitch, cube_size, stream_ptr(st.device)))
+    return st
+
+
+def _onehot_args(onehot, fmt, n, cube_size, what):
+    if fmt == FMT_NONE:
+        if onehot is not None:
+            raise RubikHipError(f"{what}: onehot given but fmt is FMT_NONE")
+        return None, 0
+    if onehot is None:
+        raise RubikHipError(f"{what}: fmt needs an output tensor")
+    if fmt == FMT_CODE:
+        return onehot, _rows(onehot, N_SLOTS[cube_size], n, what + " code")
+    R, C = STATE_DIM[cube_size]
+    if onehot.dtype != _lib.dense_dtype(fmt) or not onehot.is_cuda or not onehot.is_contiguous() or onehot.numel() < n * R * C:
+        raise RubikHipError(f"{what}: dense one-hot must be a contiguous {_lib.dense_dtype(fmt)} HIP tensor [n,{R},{C}]")
+    return onehot, 0
+
+
+def apply_moves(src, dst, actions, n, cube_size, reward=None, done=None, onehot=None, fmt=FMT_NONE):
+    """CubeEnv.step for n cubes (cube_env.py:71-111).  dst may be src (in place)."""
+    S, _, _ = _size(cube_size)
+    p_in, p_out = _rows(src, S, n, "apply_moves src"), _rows(dst, S, n, "apply_moves dst")
+    _vec(actions, n, torch.uint8, "actions")
+    _vec(reward, n, torch.float32, "reward")
+    _vec(done, n, torch.uint8, "done")
+    oh, cp = _onehot_args(onehot, fmt, n, cube_size, "apply_moves")
+    _lib.init(src.device)
+    check(lib().rc_apply_moves(ptr(src), ptr(dst), ptr(actions), n, p_in, p_out, cube_size, ptr(reward), ptr(done),
+                               ptr(oh), fmt, cp, stream_ptr(src.device)))
+
+
+def scramble(st, n, cube_size, depth, seed=0, stream_id=0, walk_offset=0, actions_in=None, actions_out=None,
+             done=None, reward=None):
+    """reset()'s scramble loop in place (cube_env.py:65-67); actions_* are [depth, pitch] uint8."""
+    S, _, _ = _size(cube_size)
+    pitch = _rows(st, S, n, "scramble")
+    ap = 0
+    for a in (actions_in, actions_out):
+        if a is not None:
+            ap = _rows(a, depth, n, "scramble actions")
+    _vec(reward, n, torch.float32, "reward")
+    _vec(done, n, torch.uint8, "done")
+    _lib.init(st.device)
+    check(lib().rc_scramble(ptr(st), n, pitch, cube_size, depth, seed, stream_id, walk_offset, ptr(actions_in),
+                            ptr(actions_out), ap, ptr(done), ptr(reward), stream_ptr(st.device)))
+
+
+def is_solved(st, n, cube_size, done=None, reward=None):
+    S, _, _ = _size(cube_size)
+    pitch = _rows(st, S, n, "is_solved")
+    _vec(reward, n, torch.float32, "reward")
+    _vec(done, n, torch.uint8, "done")
+    _lib.init(st.device)
+    check(lib().rc_is_solved(ptr(st), n, pitch, cube_size, ptr(done), ptr(reward), stream_ptr(st.device)))
+
+
+def encode(st, n, cube_size, onehot, fmt):
+    S, _, _ = _size(cube_size)
+    pitch = _rows(st, S, n, "encode")
+    oh, cp = _onehot_args(onehot, fmt, n, cube_size, "encode")
+    _lib.init(st.device)
+    check(lib().rc_encode(ptr(st), n, pitch, cube_size, ptr(oh), fmt, cp, stream_ptr(st.device)))
+
+
+def onehot_from_code(code, n, cube_size, onehot):
+    _size(cube_size)
+    cp = _rows(code, N_SLOTS[cube_size], n, "onehot_from_code")
+    fmt = _lib.fmt_of(onehot.dtype)
+    _onehot_args(onehot, fmt, n, cube_size, "onehot_from_code")
+    _lib.init(code.device)
+    check(lib().rc_onehot_from_code(ptr(code), n, cp, cube_size, ptr(onehot), fmt, stream_ptr(code.device)))
+
+
+def expand_children(st, n, cube_size, children=None, child_solved=None, child_code=None):
+    """children [A,S,pitch], child_solved [A,pitch], child_code [A,SLOTS,pitch] (same pitch)."""
+    S, A, SL = _size(cube_size)
+    p_in = _rows(st, S, n, "expand src")
+    pitches = set()
+    if children is not None:
+        pitches.add(_rows(children, S, n, "children"))
+        if children.shape[0] != A:
+            raise RubikHipError("children: first dim must be A")
+    if child_solved is not None:
+        pitches.add(_rows(child_solved, A, n, "child_solved"))
+    if child_code is not None:
+        pitches.add(_rows(child_code, SL, n, "child_code"))
+        if child_code.shape[0] != A:
+            raise RubikHipError("child_code: first dim must be A")
+    if len(pitches) != 1:
+        raise RubikHipError("expand_children: outputs must share one pitch")
+    _lib.init(st.device)
+    check(lib().rc_expand_children(ptr(st), n, p_in, cube_size, ptr(children), ptr(child_solved), ptr(child_code),
+                                   pitches.pop(), stream_ptr(st.device)))
+
+
+def adi_generate(n_walks, depth, cube_size, pitch, device, seed=0, stream_id=0, walk_offset=0, actions_in=None,
+                 actions_out=None, parents=None, parent_code=None, children=None, child_code=None, child_solved=None):
+    """ADI walks + expansion (cube_env.py:177-194,212-236); see include/rubikhip.h for layouts."""
+    S, A, SL = _size(cube_size)
+    shapes = dict(actions_in=(depth, pitch), actions_out=(depth, pitch), parents=(depth, S, pitch),
+                  parent_code=(depth, SL, pitch), children=(depth, A, S, pitch), child_code=(depth, A, SL, pitch),
+                  child_solved=(depth, A, pitch))
+    bufs = dict(actions_in=actions_in, actions_out=actions_out, parents=parents, parent_code=parent_code,
+                children=children, child_code=child_code, child_solved=child_solved)
+    for k, t in bufs.items():
+        if t is not None and (tuple(t.shape) != shapes[k] or t.dtype != torch.uint8 or not t.is_cuda or not t.is_contiguous()):
+            raise RubikHipError(f"adi_generate: {k} must be a contiguous uint8 HIP tensor of shape {shapes[k]}")
+    dev = torch.device(device)
+    _lib.init(dev)
+    check(lib().rc_adi_generate(seed, stream_id, walk_offset, n_walks, depth, cube_size, pitch, ptr(actions_in),
+                                ptr(actions_out), ptr(parents), ptr(parent_code), ptr(children), ptr(child_code),
+                                ptr(child_solved), stream_ptr(dev)))
+
+
+def adi_targets(child_value, child_solved, n, cube_size, parent_value=None, weight=None):
+    """Target value / policy / error (cube_env.py:229-232,239-251).
+    child_value [A,pitch] f32, child_solved [A,pitch] u8, parent_value [n] f32, weight [n] f64."""
+    _, A, _ = _size(cube_size)
+    pitch = child_value.shape[-1]
+    if child_value.dtype != torch.float32 or tuple(child_value.shape) != (A, pitch) or not child_value.is_contiguous():
+        raise RubikHipError("adi_targets: child_value must be contiguous float32 [A, pitch]")
+    if child_solved.dtype != torch.uint8 or tuple(child_solved.shape) != (A, pitch) or not child_solved.is_contiguous():
+        raise RubikHipError("adi_targets: child_solved must be contiguous uint8 [A, pitch]")
+    dev = child_value.device
+    tv = torch.empty(n, dtype=torch.float32, device=dev)
+    tp = torch.empty(n, dtype=torch.int32, device=dev)
+    err = None
+    if parent_value is not None:
+        _vec(parent_value, n, torch.float32, "parent_value")
+        _vec(weight, n, torch.float64, "weight")
+        err = torch.empty(n, dtype=torch.float64, device=dev)
+    _lib.init(dev)
+    check(lib().rc_adi_targets(ptr(child_value), ptr(child_solved), ptr(parent_value), ptr(weight), n, pitch, cube_size,
+                               ptr(tv), ptr(tp), ptr(err), stream_ptr(dev)))
+    return tv, tp, err

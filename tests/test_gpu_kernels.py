@@ -1,0 +1,367 @@
+"""HIP kernels (through the C ABI) against the CPU oracle and the golden fixtures.  GPU only.
+
+Bit-exact everywhere: stickers, codes, one-hot bytes, done flags, rewards (+-1.0f exactly)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CS = [3, 2]
+S_OF = {2: 24, 3: 54}
+A_OF = {2: 6, 3: 12}
+SL_OF = {2: 7, 3: 20}
+RC_OF = {2: (7, 21), 3: (20, 24)}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from rubiks_cube_solver_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def L():
+    from rubiks_cube_solver_amd import _lib
+    return _lib
+
+
+def to_dev(states_aos, pitch=None):
+    """[n,S] numpy -> [S,pitch] device tensor (pad columns hold garbage-free zeros)."""
+    from rubiks_cube_solver_amd import _lib
+    n, S = states_aos.shape
+    pitch = pitch or _lib.pitch_for(n)
+    t = torch.zeros((S, pitch), dtype=torch.uint8)
+    t[:, :n] = torch.from_numpy(np.ascontiguousarray(states_aos.T))
+    return t.cuda()
+
+
+def to_host(t, n):
+    return np.ascontiguousarray(t[..., :n].cpu().numpy().swapaxes(-1, -2))
+
+
+def random_states(oracle, cs, n, depth, seed):
+    rng = np.random.default_rng(seed)
+    acts = rng.integers(0, A_OF[cs], (n, depth), dtype=np.uint8)
+    out = oracle.adi(cs, n, depth, actions_in=acts, want_children=False)
+    return out["parents"][:, -1].copy()
+
+
+def dense_from_code(cs, code):
+    """oracle-side dense one-hot from codes (uint8 [n,R,C])."""
+    n = len(code)
+    R, C = RC_OF[cs]
+    oh = np.zeros((n, R, C), np.uint8)
+    idx = np.arange(n)
+    for slot in range(SL_OF[cs]):
+        c = code[:, slot].astype(np.int64)
+        if cs == 3:
+            oh[idx, slot, c] = 1
+        else:
+            oh[idx, c // 3, slot * 3 + c % 3] = 1
+    return oh
+
+
+def test_library_tables_match_package(L):
+    import rubiks_cube_solver_amd as r
+    for cs in CS:
+        t, p = L.get_tables(cs), r.get_tables(cs)
+        assert (t["perm"] == p.perm).all() and (t["solved"] == p.solved).all()
+        assert (t["corner_defs"] == p.corner_defs).all() and (t["corner_code"] == p.corner_code).all()
+        assert (t["edge_code"] == p.edge_code).all()
+        if cs == 3:
+            assert (t["edge_defs"] == p.edge_defs).all()
+
+
+@pytest.mark.parametrize("cs", CS)
+@pytest.mark.parametrize("n", [1, 3, 4, 63, 257, 1000, 4099])
+def test_fill_and_is_solved(ops, oracle, cs, n):
+    st = ops.alloc_states(n, cs, "cuda")
+    st.fill_(7)
+    ops.fill_solved(st, n, cs)
+    assert (to_host(st, n) == oracle.solved(cs, n)).all()
+    done = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
+    rew = torch.zeros(n, dtype=torch.float32, device="cuda")
+    ops.is_solved(st, n, cs, done, rew)
+    assert (done.cpu().numpy() == 1).all() and (rew.cpu().numpy() == 1.0).all()
+
+
+@pytest.mark.parametrize("cs", CS)
+@pytest.mark.parametrize("variant", [1, 2, 3, 11, 12, 13])
+@pytest.mark.parametrize("n", [1, 5, 64, 255, 1021, 16384 + 3])
+def test_apply_moves_vs_oracle(ops, L, oracle, cs, variant, n):
+    L.lib().rc_set_variant(variant)
+    try:
+        S, A = S_OF[cs], A_OF[cs]
+        states = random_states(oracle, cs, n, 17, seed=n + cs)
+        rng = np.random.default_rng(n * 7 + cs)
+        acts = rng.integers(0, A, n, dtype=np.uint8)
+        # make some cubes one move from solved so done/reward see both values
+        k = max(1, n // 5)
+        states[:k] = oracle.solved(cs, k)
+        exp_st, exp_code, exp_done, exp_rew = oracle.step(cs, states, acts)
+        back = np.array([a ^ 1 for a in acts[:k]], np.uint8)
+        src = to_dev(states)
+        dst = torch.zeros_like(src)
+        a_d = torch.from_numpy(acts).cuda()
+        rew = torch.zeros(n, dtype=torch.float32, device="cuda")
+        done = torch.full((n,), 7, dtype=torch.uint8, device="cuda")
+        code = torch.zeros((SL_OF[cs], src.shape[1]), dtype=torch.uint8, device="cuda")
+        ops.apply_moves(src, dst, a_d, n, cs, rew, done, code, L.FMT_CODE)
+        assert (to_host(dst, n) == exp_st).all()
+        assert (to_host(code, n) == exp_code).all()
+        assert (done.cpu().numpy() == exp_done).all()
+        assert (rew.cpu().numpy() == exp_rew).all()
+        # second step in place undoes the first k cubes -> solved
+        acts2 = acts.copy()
+        acts2[:k] = back
+        exp2, _, exp_done2, exp_rew2 = oracle.step(cs, exp_st, acts2)
+        ops.apply_moves(dst, dst, torch.from_numpy(acts2).cuda(), n, cs, rew, done)
+        assert (to_host(dst, n) == exp2).all()
+        assert (done.cpu().numpy() == exp_done2).all() and exp_done2[:k].all()
+        assert (rew.cpu().numpy() == exp_rew2).all()
+        assert L.read_status() == 0
+    finally:
+        L.lib().rc_set_variant(0)
+
+
+@pytest.mark.parametrize("cs", CS)
+@pytest.mark.parametrize("fmt_name", ["U8", "F16", "F32"])
+@pytest.mark.parametrize("n", [1, 6, 1023, 1024, 1025, 5000])
+def test_apply_moves_dense_onehot(ops, L, oracle, cs, fmt_name, n):
+    fmt = getattr(L, "FMT_" + fmt_name)
+    R, C = RC_OF[cs]
+    states = random_states(oracle, cs, n, 9, seed=100 + n)
+    acts = np.random.default_rng(n).integers(0, A_OF[cs], n, dtype=np.uint8)
+    exp_st, exp_code, exp_done, exp_rew = oracle.step(cs, states, acts)
+    src = to_dev(states)
+    dst = torch.zeros_like(src)
+    oh = torch.full((n, R, C), 3, dtype=L.dense_dtype(fmt), device="cuda")
+    rew = torch.zeros(n, dtype=torch.float32, device="cuda")
+    done = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    ops.apply_moves(src, dst, torch.from_numpy(acts).cuda(), n, cs, rew, done, oh, fmt)
+    assert (to_host(dst, n) == exp_st).all()
+    exp_oh = dense_from_code(cs, exp_code)
+    _, oracle_oh = oracle.encode(cs, exp_st)
+    assert (exp_oh == oracle_oh).all()
+    got = oh.cpu().numpy()
+    assert (got == exp_oh.astype(got.dtype)).all()
+    assert (done.cpu().numpy() == exp_done).all() and (rew.cpu().numpy() == exp_rew).all()
+    # standalone encode and code -> dense agree
+    oh2 = torch.full_like(oh, 5)
+    ops.encode(dst, n, cs, oh2, fmt)
+    assert torch.equal(oh, oh2)
+    code = torch.zeros((SL_OF[cs], src.shape[1]), dtype=torch.uint8, device="cuda")
+    ops.encode(dst, n, cs, code, L.FMT_CODE)
+    assert (to_host(code, n) == exp_code).all()
+    oh3 = torch.full_like(oh, 5)
+    ops.onehot_from_code(code, n, cs, oh3)
+    assert torch.equal(oh, oh3)
+
+
+def test_golden_walks_on_gpu(ops, L, golden):
+    """G3 replayed step by step through rc_apply_moves: stickers, one-hot column, done, reward."""
+    g = golden("walks_333")
+    W, D = g["actions"].shape
+    st = ops.alloc_states(W, 3, "cuda")
+    ops.fill_solved(st, W, 3)
+    code = torch.zeros((20, st.shape[1]), dtype=torch.uint8, device="cuda")
+    rew = torch.zeros(W, dtype=torch.float32, device="cuda")
+    done = torch.zeros(W, dtype=torch.uint8, device="cuda")
+    acts = torch.from_numpy(np.ascontiguousarray(g["actions"].T)).cuda()
+    for d in range(D):
+        ops.apply_moves(st, st, acts[d].contiguous(), W, 3, rew, done, code, L.FMT_CODE)
+        assert (to_host(st, W) == g["stickers"][:, d]).all()
+        assert (to_host(code, W) == g["cols"][:, d]).all()
+        assert (done.cpu().numpy() == g["done"][:, d]).all()
+        assert (rew.cpu().numpy() == g["reward"][:, d]).all()
+
+
+def test_golden_encode_arbitrary_colourings(ops, L, golden):
+    g = golden("encode_333")
+    n = len(g["stickers"])
+    st = to_dev(g["stickers"])
+    code = torch.zeros((20, st.shape[1]), dtype=torch.uint8, device="cuda")
+    ops.encode(st, n, 3, code, L.FMT_CODE)
+    assert (to_host(code, n) == g["cols"]).all()
+    done = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    ops.is_solved(st, n, 3, done)
+    assert (done.cpu().numpy() == g["solved"]).all()
+    rec = to_dev(g["recoloured"])
+    done = torch.zeros(len(g["recoloured"]), dtype=torch.uint8, device="cuda")
+    ops.is_solved(rec, len(g["recoloured"]), 3, done)
+    assert (done.cpu().numpy() == g["recoloured_solved"]).all()
+
+
+@pytest.mark.parametrize("cs", CS)
+@pytest.mark.parametrize("n", [1, 37, 512, 4096, 70000])
+def test_expand_children(ops, oracle, cs, n):
+    S, A, SL = S_OF[cs], A_OF[cs], SL_OF[cs]
+    states = random_states(oracle, cs, n, 20, seed=n)
+    states[: max(1, n // 7)] = oracle.step(cs, oracle.solved(cs, max(1, n // 7)), np.arange(max(1, n // 7)) % A)[0]
+    ch, cc, cso = oracle.expand(cs, states, threads=4)
+    src = to_dev(states)
+    p = src.shape[1]
+    children = torch.zeros((A, S, p), dtype=torch.uint8, device="cuda")
+    solved = torch.zeros((A, p), dtype=torch.uint8, device="cuda")
+    code = torch.zeros((A, SL, p), dtype=torch.uint8, device="cuda")
+    ops.expand_children(src, n, cs, children, solved, code)
+    assert (to_host(children, n).transpose(1, 0, 2) == ch).all()      # [n, A, S]
+    assert (solved[:, :n].cpu().numpy().T == cso).all() and cso.any()
+    assert (to_host(code, n).transpose(1, 0, 2) == cc).all()
+    solved2 = torch.zeros_like(solved)
+    ops.expand_children(src, n, cs, child_solved=solved2)
+    assert torch.equal(solved[:, :n], solved2[:, :n])
+
+
+def test_golden_expand(ops, golden):
+    g = golden("expand_333")
+    n = len(g["leaves"])
+    src = to_dev(g["leaves"])
+    p = src.shape[1]
+    children = torch.zeros((12, 54, p), dtype=torch.uint8, device="cuda")
+    solved = torch.zeros((12, p), dtype=torch.uint8, device="cuda")
+    code = torch.zeros((12, 20, p), dtype=torch.uint8, device="cuda")
+    ops.expand_children(src, n, 3, children, solved, code)
+    assert (to_host(children, n).transpose(1, 0, 2) == g["child_stickers"]).all()
+    assert (to_host(code, n).transpose(1, 0, 2) == g["child_cols"]).all()
+    assert (solved[:, :n].cpu().numpy().T == g["child_done"]).all()
+
+
+@pytest.mark.parametrize("cs", CS)
+@pytest.mark.parametrize("n_walks,depth", [(1, 1), (5, 3), (300, 30), (5000, 7)])
+@pytest.mark.parametrize("replay", [False, True])
+def test_adi_generate(ops, L, oracle, cs, n_walks, depth, replay):
+    S, A, SL = S_OF[cs], A_OF[cs], SL_OF[cs]
+    p = L.pitch_for(n_walks)
+    z = lambda *shape: torch.zeros(shape, dtype=torch.uint8, device="cuda")
+    bufs = dict(actions_out=z(depth, p), parents=z(depth, S, p), parent_code=z(depth, SL, p),
+                children=z(depth, A, S, p), child_code=z(depth, A, SL, p), child_solved=z(depth, A, p))
+    kw = {}
+    exp_kw = dict(seed=2024, stream=3, walk0=11)
+    if replay:
+        acts = np.random.default_rng(5).integers(0, A, (n_walks, depth), dtype=np.uint8)
+        a_in = z(depth, p)
+        a_in[:, :n_walks] = torch.from_numpy(np.ascontiguousarray(acts.T)).cuda()
+        kw["actions_in"] = a_in
+        exp_kw["actions_in"] = acts
+    exp = oracle.adi(cs, n_walks, depth, threads=4, **exp_kw)
+    ops.adi_generate(n_walks, depth, cs, p, "cuda", seed=2024, stream_id=3, walk_offset=11, **kw, **bufs)
+    assert L.read_status() == 0
+    assert (bufs["actions_out"][:, :n_walks].cpu().numpy().T == exp["actions"]).all()
+    assert (to_host(bufs["parents"], n_walks).transpose(1, 0, 2) == exp["parents"]).all()
+    assert (to_host(bufs["parent_code"], n_walks).transpose(1, 0, 2) == exp["parent_code"]).all()
+    assert (to_host(bufs["children"], n_walks).transpose(2, 0, 1, 3) == exp["children"]).all()
+    assert (to_host(bufs["child_code"], n_walks).transpose(2, 0, 1, 3) == exp["child_code"]).all()
+    assert (bufs["child_solved"][..., :n_walks].cpu().numpy().transpose(2, 0, 1) == exp["child_solved"]).all()
+    # subsets of outputs give the same bytes
+    cs2 = z(depth, A, p)
+    ops.adi_generate(n_walks, depth, cs, p, "cuda", seed=2024, stream_id=3, walk_offset=11, child_solved=cs2, **kw)
+    assert torch.equal(cs2[..., :n_walks], bufs["child_solved"][..., :n_walks])
+
+
+@pytest.mark.parametrize("cs", CS)
+def test_scramble_matches_adi_and_reset_golden(ops, L, oracle, golden, cs):
+    n, depth = 777, 25
+    st = ops.alloc_states(n, cs, "cuda")
+    ops.fill_solved(st, n, cs)
+    p = st.shape[1]
+    a_out = torch.zeros((depth, p), dtype=torch.uint8, device="cuda")
+    done = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    ops.scramble(st, n, cs, depth, seed=9, stream_id=1, walk_offset=5, actions_out=a_out, done=done)
+    exp = oracle.adi(cs, n, depth, seed=9, stream=1, walk0=5, want_children=False)
+    assert (a_out[:, :n].cpu().numpy().T == exp["actions"]).all()
+    assert (to_host(st, n) == exp["parents"][:, -1]).all()
+    assert (done.cpu().numpy() == oracle.is_solved(cs, exp["parents"][:, -1])).all()
+    if cs == 3:  # G4: the reference's reset(seed, k) action draws replayed on the device
+        g = golden("reset_333")
+        ns, nk = g["actions"].shape[:2]
+        for j in (0, 4, 29):
+            k = int(g["ks"][j])
+            st = ops.alloc_states(ns, 3, "cuda")
+            ops.fill_solved(st, ns, 3)
+            a_in = torch.zeros((k, st.shape[1]), dtype=torch.uint8, device="cuda")
+            a_in[:, :ns] = torch.from_numpy(np.ascontiguousarray(g["actions"][:, j, :k].T)).cuda()
+            ops.scramble(st, ns, 3, k, actions_in=a_in)
+            assert (to_host(st, ns) == g["stickers"][:, j]).all()
+
+
+def test_bad_action_sets_status(ops, L):
+    n = 100
+    st = ops.alloc_states(n, 3, "cuda")
+    ops.fill_solved(st, n, 3)
+    for bad in (12, 13, 200, 255):
+        acts = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        acts[37] = bad
+        ops.apply_moves(st, st, acts, n, 3)
+        assert L.read_status() & L.STATUS_BAD_ACTION
+        assert L.read_status() == 0
+    st2 = ops.alloc_states(n, 2, "cuda")
+    ops.fill_solved(st2, n, 2)
+    for bad in (6, 7, 11, 12, 99):
+        acts = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        acts[5] = bad
+        ops.apply_moves(st2, st2, acts, n, 2)
+        assert L.read_status() & L.STATUS_BAD_ACTION
+
+
+def test_argument_errors(ops, L):
+    st = ops.alloc_states(10, 3, "cuda")
+    with pytest.raises(NotImplementedError):
+        ops.alloc_states(10, 4, "cuda")
+    with pytest.raises(L.RubikHipError):
+        ops.fill_solved(st[:, :7], 7, 3)            # non-contiguous / bad pitch
+    with pytest.raises(L.RubikHipError):
+        ops.apply_moves(st, st, torch.zeros(10, dtype=torch.int64, device="cuda"), 10, 3)
+    with pytest.raises(L.RubikHipError):
+        ops.fill_solved(torch.zeros((54, 256), dtype=torch.uint8), 10, 3)   # host tensor
+    assert L.lib().rc_fill_solved(None, 1, 256, 3, None) == -1
+    assert b"rc_fill_solved" in L.lib().rc_last_error()
+    assert L.lib().rc_fill_solved(L.ptr(st), 1, 256, 5, None) == -1
+
+
+@pytest.mark.parametrize("cs", CS)
+def test_adi_targets(ops, cs):
+    A = A_OF[cs]
+    n, p = 1000, 1024
+    g = torch.Generator().manual_seed(1)
+    cv = torch.randn((A, p), generator=g)
+    cv[:, 5] = 0.25                      # all equal -> first index
+    cv[3, 6] = cv[7 % A, 6] = 9.0        # tie -> lowest index
+    solved = (torch.rand((A, p), generator=g) < 0.05).to(torch.uint8)
+    pv = torch.randn(n, generator=g)
+    d = torch.randint(1, 31, (n,), generator=g)
+    w = torch.tensor([float(int(x) ** (-0.3)) for x in d], dtype=torch.float64)
+    tv, tp, err = ops.adi_targets(cv.cuda(), solved.cuda(), n, cs, pv.cuda(), w.cuda())
+    cvn, sn = cv.numpy()[:, :n], solved.numpy()[:, :n].astype(bool)
+    v = cvn + np.float32(-1.0)
+    exp_tp = np.where(sn.any(0), np.argmax(sn, 0), np.argmax(v, 0))
+    exp_tv = np.where(sn.any(0), np.float32(1.0), v.max(0)).astype(np.float32)
+    assert (tp.cpu().numpy() == exp_tp).all()
+    assert (tv.cpu().numpy() == exp_tv).all()
+    exp_err = np.abs(pv.numpy().astype(np.float64) - exp_tv.astype(np.float64)) * w.numpy()
+    assert (err.cpu().numpy() == exp_err).all()
+
+
+def test_full_size_properties(ops, L):
+    """BASELINE sizes (4M cubes): order-4 and inverse identities, checksum of checksums."""
+    n = 1 << 22
+    st = ops.alloc_states(n, 3, "cuda")
+    ops.fill_solved(st, n, 3)
+    ops.scramble(st, n, 3, 20, seed=1234)
+    ref = st.clone()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    acts = torch.randint(0, 12, (n,), generator=g, device="cuda", dtype=torch.uint8)
+    tmp = torch.empty_like(st)
+    ops.apply_moves(st, tmp, acts, n, 3)
+    assert not torch.equal(tmp[:, :n], ref[:, :n])
+    assert torch.equal(tmp[:, :n].to(torch.int32).sum(0), ref[:, :n].to(torch.int32).sum(0))  # a move permutes stickers
+    ops.apply_moves(tmp, st, acts ^ 1, n, 3)                      # X then X' = identity
+    assert torch.equal(st[:, :n], ref[:, :n])
+    for _ in range(4):                                             # X^4 = identity
+        ops.apply_moves(st, st, acts, n, 3)
+    assert torch.equal(st[:, :n], ref[:, :n])
+    done = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    ops.is_solved(st, n, 3, done)
+    assert int(done.sum()) < n // 1000
+    assert L.read_status() == 0

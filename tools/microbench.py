@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks on one GPU (development tool; bench.py is the contract)."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from rubiks_cube_solver_amd import _lib, ops
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    out = []
+    L = _lib.lib()
+    which = sys.argv[1:] or ["step", "code", "dense", "adi", "expand", "copy"]
+    n = 1 << 22
+    a = ops.alloc_states(n, 3, "cuda")
+    b = torch.empty_like(a)
+    ops.fill_solved(a, n, 3)
+    ops.scramble(a, n, 3, 20, seed=1234)
+    acts = torch.randint(0, 12, (n,), dtype=torch.uint8, device="cuda")
+    done = torch.empty(n, dtype=torch.uint8, device="cuda")
+    rew = torch.empty(n, dtype=torch.float32, device="cuda")
+    if "copy" in which:
+        t = timeit(lambda: b.copy_(a))
+        out.append(dict(k="torch_copy_54rows", ms=t * 1e3, GBps=2 * a.numel() / t / 1e9))
+    if "step" in which:
+        for var in (1, 2, 3, 11, 12, 13):
+            L.rc_set_variant(var)
+            buf = [a, b]
+            def f():
+                ops.apply_moves(buf[0], buf[1], acts, n, 3, None, done)
+                buf.reverse()
+            t = timeit(f)
+            out.append(dict(k=f"step_v{var}", ms=t * 1e3, Gsteps=n / t / 1e9, GBps=110 * n / t / 1e9))
+            def f2():
+                ops.apply_moves(buf[0], buf[1], acts, n, 3, rew, done)
+                buf.reverse()
+            t = timeit(f2)
+            out.append(dict(k=f"step_reward_v{var}", ms=t * 1e3, Gsteps=n / t / 1e9, GBps=114 * n / t / 1e9))
+            def f3():
+                ops.apply_moves(a, a, acts, n, 3, None, done)
+            t = timeit(f3)
+            out.append(dict(k=f"step_inplace_v{var}", ms=t * 1e3, Gsteps=n / t / 1e9, GBps=110 * n / t / 1e9))
+        L.rc_set_variant(0)
+    if "code" in which:
+        code = torch.empty((20, a.shape[1]), dtype=torch.uint8, device="cuda")
+        for var in (1, 2, 3):
+            L.rc_set_variant(var)
+            buf = [a, b]
+            def f():
+                ops.apply_moves(buf[0], buf[1], acts, n, 3, None, done, code, _lib.FMT_CODE)
+                buf.reverse()
+            t = timeit(f)
+            out.append(dict(k=f"step_code_v{var}", ms=t * 1e3, Gsteps=n / t / 1e9, GBps=130 * n / t / 1e9))
+        L.rc_set_variant(0)
+    if "dense" in which:
+        m = 1 << 20
+        for fmt, name, bpc in ((_lib.FMT_U8, "u8", 480), (_lib.FMT_F16, "f16", 960), (_lib.FMT_F32, "f32", 1920)):
+            oh = torch.empty((m, 20, 24), dtype=_lib.dense_dtype(fmt), device="cuda")
+            t = timeit(lambda: ops.apply_moves(a, b, acts, m, 3, None, done, oh, fmt), iters=10)
+            out.append(dict(k=f"step_dense_{name}_1M", ms=t * 1e3, Gsteps=m / t / 1e9, GBps=(110 + bpc) * m / t / 1e9))
+            del oh
+    if "adi" in which:
+        W, D = 100_000, 30
+        p = _lib.pitch_for(W)
+        z = lambda *s: torch.empty(s, dtype=torch.uint8, device="cuda")
+        bufs = dict(actions_out=z(D, p), parents=z(D, 54, p), children=z(D, 12, 54, p), child_solved=z(D, 12, p))
+        t = timeit(lambda: ops.adi_generate(W, D, 3, p, "cuda", seed=2024, **bufs), iters=5, warm=2)
+        out.append(dict(k="adi_100k_x30_stickers", ms=t * 1e3, Gunits=W * D / t / 1e9, GBps=715 * W * D / t / 1e9))
+        del bufs["children"]
+        bufs["child_code"] = z(D, 12, 20, p)
+        bufs["parent_code"] = z(D, 20, p)
+        t = timeit(lambda: ops.adi_generate(W, D, 3, p, "cuda", seed=2024, **bufs), iters=5, warm=2)
+        out.append(dict(k="adi_100k_x30_codes", ms=t * 1e3, Gunits=W * D / t / 1e9,
+                        GBps=(54 + 1 + 12 + 13 * 20) * W * D / t / 1e9))
+        del bufs
+    if "expand" in which:
+        for m in (4096, 1 << 20):
+            p = _lib.pitch_for(m)
+            src = a[:, :p].contiguous()
+            ch = torch.empty((12, 54, p), dtype=torch.uint8, device="cuda")
+            cs = torch.empty((12, p), dtype=torch.uint8, device="cuda")
+            t = timeit(lambda: ops.expand_children(src, m, 3, ch, cs), iters=20)
+            out.append(dict(k=f"expand_{m}", us=t * 1e6, GBps=(54 + 13 * 54 + 12) * m / t / 1e9))
+    for r in out:
+        print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}))
+
+
+if __name__ == "__main__":
+    main()

@@ -9,9 +9,14 @@
  * Conventions
  *   - All buffers are DEVICE memory owned by the caller (e.g. PyTorch-ROCm tensors); the
  *     library allocates nothing but its constant tables and one status word per device.
- *   - Cube states are structure-of-arrays uint8: sticker s of cube n lives at
- *     st[s * pitch + n]; S = 54 (cube_size 3) or 24 (cube_size 2) rows; values 0..5.
- *     pitch >= n_cubes, pitch % 16 == 0, base pointers 16-byte aligned.
+ *   - State layout.  Cube states are structure-of-arrays uint8, values 0..5, S = 54
+ *     (cube_size 3) or 24 (cube_size 2) rows, in TILES of `pitch` cubes:
+ *         sticker s of cube n lives at st[(n / pitch) * S * pitch + s * pitch + n % pitch].
+ *     One tile (pitch >= n_cubes, pitch % 16 == 0) is plain SoA, st[s * pitch + n].  Several
+ *     tiles need a power-of-two pitch >= 1024; 16384 measured best on MI355X at 4M cubes
+ *     (+12..24 % HBM throughput over one 4M-wide tile: every wave's 54 row segments then sit
+ *     within 54 * pitch bytes).  RC_FMT_CODE buffers are tiled the same way with SLOTS rows.
+ *     Buffers described as "plain" below are one tile.  Base pointers are 16-byte aligned.
  *   - actions are uint8 in the env's action order U,U',F,F',R,R'[,D,D',B,B',L,L']
  *     (gym-cube/gym_cube/envs/cube_env.py:24-28); A = 12 | 6.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
@@ -25,7 +30,7 @@
  *
  * One-hot formats (`fmt`)
  *   RC_FMT_NONE   nothing written
- *   RC_FMT_CODE   compact, lossless: uint8 code[slot * pitch + n], slot = 0..19 | 0..6,
+ *   RC_FMT_CODE   compact, lossless: uint8 code[slot * pitch + n] (tiled like states), slot = 0..19 | 0..6,
  *                 code = piece*3+ori (corner slots) or piece*2+ori (edge slots)
  *                 (getOP_3, assets/py333.py:224-227).  3x3x3: one-hot column of row `slot`
  *                 (pos_to_state_3, py333.py:235-246).  2x2x2: row = code/3,
@@ -110,8 +115,9 @@ int rc_encode(const uint8_t *st, int64_t n_cubes, int64_t pitch, int cube_size, 
 int rc_onehot_from_code(const uint8_t *code, int64_t n_cubes, int64_t code_pitch, int cube_size,
                         void *onehot, int fmt, void *stream);
 
-/* All A children of every cube: children[(a*S + s) * pitch_out + n], child_solved[a * pitch_out + n],
- * child_code[(a*SLOTS + slot) * pitch_out + n] (NULL to skip).  Replaces the child loops of
+/* All A children of every cube, into PLAIN buffers (pitch_out >= n_cubes, % 16 == 0):
+ * children[(a*S + s) * pitch_out + n], child_solved[a * pitch_out + n],
+ * child_code[(a*SLOTS + slot) * pitch_out + n] (NULL to skip).  `in` may be tiled.  Replaces the child loops of
  * CubeEnv.get_target_value (cube_env.py:212-236) and MCTS.expand (mcts.py:96-101). */
 int rc_expand_children(const uint8_t *in, int64_t n_cubes, int64_t pitch_in, int cube_size,
                        uint8_t *children, uint8_t *child_solved, uint8_t *child_code,
@@ -129,7 +135,7 @@ int rc_expand_children(const uint8_t *in, int64_t n_cubes, int64_t pitch_in, int
  *   children     [depth][A][S][pitch]           (NULL to skip)
  *   child_code   [depth][A][SLOTS][pitch]       (NULL to skip)
  *   child_solved [depth][A][pitch]              (NULL to skip)
- * pitch >= n_walks, pitch % 16 == 0. */
+ * All buffers are plain: pitch >= n_walks, pitch % 16 == 0. */
 int rc_adi_generate(uint64_t seed, uint64_t stream_id, int64_t walk_offset, int64_t n_walks,
                     int depth, int cube_size, int64_t pitch, const uint8_t *actions_in,
                     uint8_t *actions_out, uint8_t *parents, uint8_t *parent_code,

@@ -29,13 +29,24 @@ namespace {
 constexpr int kWave = 64;
 __device__ uint32_t g_status;  // RC_STATUS_* bits, per device (one code object instance per device)
 
+// Tiled structure-of-arrays addressing (include/rubikhip.h "State layout"): cube n of a buffer
+// with `rows` rows lives in tile n / pitch; tiles follow each other, [tile][row][pitch].
+// `shift` = log2(pitch) when the buffer has several tiles, 63 when it has one (then tile = 0 and
+// any pitch % 16 == 0 works).  g0 is a wave-uniform cube index that is a multiple of the wave's
+// span (<= 1024 cubes), so a wave never straddles tiles (multi-tile pitch is a multiple of 1024).
+__device__ __forceinline__ int64_t tile_off(int64_t g0, int64_t pitch, int shift, int rows) {
+    return g0 + (g0 >> shift) * (rows - 1) * pitch;
+}
+
 // ------------------------------------------------------------------------------ fill
 template <class T>
-__global__ void __launch_bounds__(256) k_fill_solved(uint8_t *base, int64_t n, int64_t pitch) {
-    const int64_t n0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
-    if (n0 >= n) return;
+__global__ void __launch_bounds__(kWave) k_fill_solved(uint8_t *base, int64_t n, int64_t pitch, int shift) {
+    const int64_t g0 = (int64_t)blockIdx.x * (kWave * 16);
+    const uint32_t lo = threadIdx.x * 16;
+    if (g0 + lo >= n) return;
+    uint8_t *row = base + tile_off(g0, pitch, shift, T::S);
 #pragma unroll
-    for (int s = 0; s < T::S; ++s) st<4, false>(base + s * pitch + n0, splat<4>((uint32_t)(s / T::FACE) * 0x01010101u));
+    for (int s = 0; s < T::S; ++s) { st<4, false>(row + lo, splat<4>((uint32_t)(s / T::FACE) * 0x01010101u)); row += pitch; }
 }
 
 // ------------------------------------------------------------------------------ step
@@ -48,6 +59,7 @@ struct StepArgs {
     uint8_t *done;
     uint8_t *code;
     int64_t code_pitch;
+    int sh_in, sh_out, sh_code;   // tile shifts (see tile_off)
 };
 
 template <int V>
@@ -74,7 +86,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(StepArgs a) {
     if (n0 >= a.n) return;
     Pk<V> s[T::S];
     {
-        const uint8_t *row = a.in + g0;
+        const uint8_t *row = a.in + tile_off(g0, a.pitch_in, a.sh_in, T::S);
 #pragma unroll
         for (int i = 0; i < T::S; ++i) { s[i] = ld<V, NT>(row + lo); row += a.pitch_in; }
     }
@@ -89,7 +101,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(StepArgs a) {
         for (int i = 0; i < T::S; ++i) s[i] = o[i];
     }
     if constexpr (STORE) {
-        uint8_t *row = a.out + g0;
+        uint8_t *row = a.out + tile_off(g0, a.pitch_out, a.sh_out, T::S);
 #pragma unroll
         for (int i = 0; i < T::S; ++i) { st<V, NT>(row + lo, s[i]); row += a.pitch_out; }
     }
@@ -101,7 +113,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(StepArgs a) {
     if constexpr (CODE) {
         Pk<V> c[T::SLOTS];
         encode<T, V>(s, c);
-        uint8_t *row = a.code + g0;
+        uint8_t *row = a.code + tile_off(g0, a.code_pitch, a.sh_code, T::SLOTS);
 #pragma unroll
         for (int p = 0; p < T::SLOTS; ++p) { st<V, NT>(row + lo, c[p]); row += a.code_pitch; }
     }
@@ -121,7 +133,7 @@ __global__ void __launch_bounds__(kDenseBlock) k_step_dense(StepArgs a, E *dense
     if (n0 < a.n) {
         Pk<1> s[T::S];
         {
-            const uint8_t *row = a.in + tile0;
+            const uint8_t *row = a.in + tile_off(tile0, a.pitch_in, a.sh_in, T::S);
 #pragma unroll
             for (int i = 0; i < T::S; ++i) { s[i] = ld<1, false>(row + lo); row += a.pitch_in; }
         }
@@ -136,7 +148,7 @@ __global__ void __launch_bounds__(kDenseBlock) k_step_dense(StepArgs a, E *dense
             for (int i = 0; i < T::S; ++i) s[i] = o[i];
         }
         if constexpr (STORE) {
-            uint8_t *row = a.out + tile0;
+            uint8_t *row = a.out + tile_off(tile0, a.pitch_out, a.sh_out, T::S);
 #pragma unroll
             for (int i = 0; i < T::S; ++i) { st<1, false>(row + lo, s[i]); row += a.pitch_out; }
         }
@@ -157,14 +169,14 @@ __global__ void __launch_bounds__(kDenseBlock) k_step_dense(StepArgs a, E *dense
 }
 
 template <class T, class E>
-__global__ void __launch_bounds__(kDenseBlock) k_code_to_dense(const uint8_t *code, int64_t n, int64_t code_pitch, E *dense) {
+__global__ void __launch_bounds__(kDenseBlock) k_code_to_dense(const uint8_t *code, int64_t n, int64_t code_pitch, int shift, E *dense) {
     __shared__ __attribute__((aligned(16))) uint8_t lds_code[T::SLOTS * kDenseTp];
     const int64_t tile0 = (int64_t)blockIdx.x * kDenseTile;
     const int64_t n0 = tile0 + threadIdx.x * 4;
     if (n0 < n) {
+        const uint8_t *row = code + tile_off(tile0, code_pitch, shift, T::SLOTS) + threadIdx.x * 4;
 #pragma unroll
-        for (int p = 0; p < T::SLOTS; ++p)
-            *reinterpret_cast<uint32_t *>(lds_code + p * kDenseTp + threadIdx.x * 4) = ld<1, false>(code + p * code_pitch + n0).d[0];
+        for (int p = 0; p < T::SLOTS; ++p) { *reinterpret_cast<uint32_t *>(lds_code + p * kDenseTp + threadIdx.x * 4) = ld<1, false>(row).d[0]; row += code_pitch; }
     }
     __syncthreads();
     const int64_t left = n - tile0;
@@ -178,7 +190,7 @@ struct ExpandArgs {
     int64_t n, pitch_in;
     uint8_t *children, *child_solved, *child_code;
     int64_t pitch_out;
-    int parts;
+    int parts, sh_in;
 };
 
 // Row addressing: every row pointer handed to these helpers is WAVE-UNIFORM (kernel argument +
@@ -234,7 +246,7 @@ __global__ void __launch_bounds__(kWave) k_expand(ExpandArgs a) {
     if (g0 + lo >= a.n) return;
     Pk<V> s[T::S];
     {
-        const uint8_t *row = a.in + g0;
+        const uint8_t *row = a.in + tile_off(g0, a.pitch_in, a.sh_in, T::S);
 #pragma unroll
         for (int i = 0; i < T::S; ++i) { s[i] = ld<V, false>(row + lo); row += a.pitch_in; }
     }
@@ -320,7 +332,7 @@ __global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
 struct ScrambleArgs {
     uint8_t *st;
     int64_t n, pitch;
-    int depth;
+    int depth, shift;
     uint64_t seed, stream_id;
     int64_t walk_offset;
     const uint8_t *actions_in;
@@ -339,7 +351,7 @@ __global__ void __launch_bounds__(kWave) k_scramble(ScrambleArgs a) {
     if (n0 >= a.n) return;
     Pk<V> s[T::S];
     {
-        const uint8_t *row = a.st + g0;
+        const uint8_t *row = a.st + tile_off(g0, a.pitch, a.shift, T::S);
 #pragma unroll
         for (int i = 0; i < T::S; ++i) { s[i] = ld<V, false>(row + lo); row += a.pitch; }
     }
@@ -368,7 +380,7 @@ __global__ void __launch_bounds__(kWave) k_scramble(ScrambleArgs a) {
         for (int i = 0; i < T::S; ++i) s[i] = o[i];
     }
     {
-        uint8_t *row = a.st + g0;
+        uint8_t *row = a.st + tile_off(g0, a.pitch, a.shift, T::S);
 #pragma unroll
         for (int i = 0; i < T::S; ++i) { st<V, false>(row + lo, s[i]); row += a.pitch; }
     }
@@ -415,7 +427,17 @@ int fail(int code, const char *fmt, const char *detail = "") {
     } while (0)
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-inline bool bad_pitch(int64_t pitch, int64_t n) { return pitch < n || (pitch & 15) != 0; }
+inline bool bad_pitch(int64_t pitch, int64_t n) { return pitch < n || (pitch & 15) != 0; }  // single-tile buffers
+// state / code buffers may be tiled: one tile (pitch >= n, pitch % 16 == 0) or several
+// (pitch a power of two >= 1024).  Returns the shift for tile_off, or -1 if the pitch is bad.
+inline int tile_shift(int64_t pitch, int64_t n) {
+    if (pitch <= 0 || (pitch & 15) != 0) return -1;
+    if (n <= pitch) return 63;
+    if (pitch < 1024 || (pitch & (pitch - 1)) != 0) return -1;
+    int sh = 0;
+    while (((int64_t)1 << sh) < pitch) ++sh;
+    return sh;
+}
 inline hipStream_t S(void *s) { return static_cast<hipStream_t>(s); }
 
 template <class F>
@@ -425,12 +447,21 @@ int by_size(int cube_size, F &&f) {
     return fail(RC_EINVAL, "cube_size must be 2 or 3%s");  // NotImplementedError, cube_env.py:44
 }
 
-// pack width: widest vector that still gives the chip enough waves
+// rc_set_variant(v): v % 10 = pack width (1,2,3 -> V = 1,2,4; 0 = auto), (v / 10) % 10 = row
+// traffic policy (1 = non-temporal, 2 = default-cached, 0 = auto).
+// Measured on MI355X at 4M cubes (tools/exp/exp_step.hip): V = 2 (8 cubes per lane, dwordx2 rows)
+// beats V = 1 and V = 4; non-temporal row traffic wins once the working set no longer fits the
+// 256 MiB Infinity Cache and loses when it does (1M cubes).
 int pick_v(int64_t n) {
-    if (g_variant >= 1 && g_variant <= 3) return g_variant == 1 ? 1 : g_variant == 2 ? 2 : 4;
-    if (n >= (int64_t)1 << 21) return 4;
-    if (n >= (int64_t)1 << 19) return 2;
-    return 1;
+    const int v = g_variant % 10;
+    if (v >= 1 && v <= 3) return v == 1 ? 1 : v == 2 ? 2 : 4;
+    return n >= (int64_t)1 << 18 ? 2 : 1;
+}
+bool pick_nt(int64_t touched_bytes) {
+    const int p = (g_variant / 10) % 10;
+    if (p == 1) return true;
+    if (p == 2) return false;
+    return touched_bytes > ((int64_t)240 << 20);  // beyond the Infinity Cache: stream past it
 }
 
 template <class T, int V, bool MOVE, bool STORE, bool CODE>
@@ -439,7 +470,7 @@ int launch_step(const StepArgs &a, hipStream_t st) {
     const int64_t lanes = (a.n + 4 * V - 1) / (4 * V);
     const int64_t blocks = (lanes + BLOCK - 1) / BLOCK;
     if (blocks > 0x7fffffff) return fail(RC_EINVAL, "too many cubes for one launch%s");
-    const bool nt = g_variant >= 10;
+    const bool nt = pick_nt(a.n * T::S * ((STORE && a.out != a.in) ? 2 : 1));
     if (nt) hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, true, BLOCK>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
     else hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, false, BLOCK>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
     RC_HIP(hipGetLastError());
@@ -467,11 +498,12 @@ int launch_dense(const StepArgs &a, void *onehot, int fmt, hipStream_t st) {
     return RC_OK;
 }
 
-int check_fmt(void *onehot, int fmt, int64_t code_pitch, int64_t n) {
+int check_fmt(void *onehot, int fmt, int64_t code_pitch, int64_t n, int *sh_code) {
     if (fmt < RC_FMT_NONE || fmt > RC_FMT_F32) return fail(RC_EINVAL, "unknown one-hot format%s");
     if ((fmt == RC_FMT_NONE) != (onehot == nullptr)) return fail(RC_EINVAL, "onehot pointer and fmt disagree%s");
     if (onehot && !aligned16(onehot)) return fail(RC_EINVAL, "onehot must be 16-byte aligned%s");
-    if (fmt == RC_FMT_CODE && bad_pitch(code_pitch, n)) return fail(RC_EINVAL, "code_pitch must be >= n_cubes and a multiple of 16%s");
+    *sh_code = 63;
+    if (fmt == RC_FMT_CODE && (*sh_code = tile_shift(code_pitch, n)) < 0) return fail(RC_EINVAL, "code_pitch: need pitch %% 16 == 0 and pitch >= n_cubes, or a power-of-two tile >= 1024%s");
     return RC_OK;
 }
 
@@ -527,12 +559,13 @@ int rc_get_tables(int cube_size, uint8_t *perm, uint8_t *solved, uint8_t *corner
 }
 
 int rc_fill_solved(uint8_t *stp, int64_t n, int64_t pitch, int cube_size, void *stream) {
-    if (!stp || !aligned16(stp) || n < 0 || bad_pitch(pitch, n)) return fail(RC_EINVAL, "rc_fill_solved: bad buffer / pitch%s");
+    const int sh = tile_shift(pitch, n);
+    if (!stp || !aligned16(stp) || n < 0 || sh < 0) return fail(RC_EINVAL, "rc_fill_solved: bad buffer / pitch%s");
     if (n == 0) return RC_OK;
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
-        const int64_t blocks = ((n + 15) / 16 + 255) / 256;
-        hipLaunchKernelGGL((k_fill_solved<T>), dim3((unsigned)blocks), dim3(256), 0, S(stream), stp, n, pitch);
+        const int64_t blocks = (n + kWave * 16 - 1) / (kWave * 16);
+        hipLaunchKernelGGL((k_fill_solved<T>), dim3((unsigned)blocks), dim3(kWave), 0, S(stream), stp, n, pitch, sh);
         RC_HIP(hipGetLastError());
         return RC_OK;
     });
@@ -541,13 +574,16 @@ int rc_fill_solved(uint8_t *stp, int64_t n, int64_t pitch, int cube_size, void *
 static int step_common(const uint8_t *in, uint8_t *out, const uint8_t *actions, int64_t n, int64_t pitch_in, int64_t pitch_out,
                        int cube_size, float *reward, uint8_t *done, void *onehot, int fmt, int64_t code_pitch, void *stream,
                        bool move, bool store) {
-    if (!in || !aligned16(in) || n < 0 || bad_pitch(pitch_in, n)) return fail(RC_EINVAL, "bad input state buffer / pitch%s");
-    if (store && (!out || !aligned16(out) || bad_pitch(pitch_out, n))) return fail(RC_EINVAL, "bad output state buffer / pitch%s");
+    const int sh_in = tile_shift(pitch_in, n), sh_out = store ? tile_shift(pitch_out, n) : 63;
+    int sh_code = 63;
+    if (!in || !aligned16(in) || n < 0 || sh_in < 0) return fail(RC_EINVAL, "bad input state buffer / pitch%s");
+    if (store && (!out || !aligned16(out) || sh_out < 0)) return fail(RC_EINVAL, "bad output state buffer / pitch%s");
     if (move && !actions) return fail(RC_EINVAL, "actions is NULL%s");
     if (reward && (reinterpret_cast<uintptr_t>(reward) & 15u)) return fail(RC_EINVAL, "reward must be 16-byte aligned%s");
-    if (int rc = check_fmt(onehot, fmt, code_pitch, n)) return rc;
+    if (int rc = check_fmt(onehot, fmt, code_pitch, n, &sh_code)) return rc;
     if (n == 0) return RC_OK;
-    StepArgs a{in, out, actions, n, pitch_in, pitch_out, reward, done, fmt == RC_FMT_CODE ? static_cast<uint8_t *>(onehot) : nullptr, code_pitch};
+    StepArgs a{in, out, actions, n, pitch_in, pitch_out, reward, done, fmt == RC_FMT_CODE ? static_cast<uint8_t *>(onehot) : nullptr, code_pitch,
+               sh_in, sh_out, sh_code};
     hipStream_t st = S(stream);
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
@@ -572,14 +608,15 @@ int rc_apply_moves(const uint8_t *in, uint8_t *out, const uint8_t *actions, int6
 int rc_scramble(uint8_t *stp, int64_t n, int64_t pitch, int cube_size, int depth, uint64_t seed, uint64_t stream_id,
                 int64_t walk_offset, const uint8_t *actions_in, uint8_t *actions_out, int64_t act_pitch, uint8_t *done,
                 float *reward, void *stream) {
-    if (!stp || !aligned16(stp) || n < 0 || depth < 0 || bad_pitch(pitch, n)) return fail(RC_EINVAL, "rc_scramble: bad state buffer / pitch%s");
+    const int sh = tile_shift(pitch, n);
+    if (!stp || !aligned16(stp) || n < 0 || depth < 0 || sh < 0) return fail(RC_EINVAL, "rc_scramble: bad state buffer / pitch%s");
     if ((actions_in || actions_out) && bad_pitch(act_pitch, n)) return fail(RC_EINVAL, "rc_scramble: bad act_pitch%s");
     if ((actions_in && !aligned16(actions_in)) || (actions_out && !aligned16(actions_out))) return fail(RC_EINVAL, "rc_scramble: action buffers must be 16-byte aligned%s");
     if (reward && (reinterpret_cast<uintptr_t>(reward) & 15u)) return fail(RC_EINVAL, "reward must be 16-byte aligned%s");
     if (n == 0) return RC_OK;
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
-        ScrambleArgs a{stp, n, pitch, depth, seed, stream_id, walk_offset, actions_in, actions_out, act_pitch, done, reward};
+        ScrambleArgs a{stp, n, pitch, depth, sh, seed, stream_id, walk_offset, actions_in, actions_out, act_pitch, done, reward};
         const dim3 g((unsigned)((n + kWave * 4 - 1) / (kWave * 4))), b(kWave);
         hipLaunchKernelGGL((k_scramble<T>), g, b, 0, S(stream), a);
         RC_HIP(hipGetLastError());
@@ -598,15 +635,16 @@ int rc_encode(const uint8_t *stp, int64_t n, int64_t pitch, int cube_size, void 
 }
 
 int rc_onehot_from_code(const uint8_t *code, int64_t n, int64_t code_pitch, int cube_size, void *onehot, int fmt, void *stream) {
-    if (!code || !aligned16(code) || n < 0 || bad_pitch(code_pitch, n)) return fail(RC_EINVAL, "bad code buffer / pitch%s");
+    const int sh = tile_shift(code_pitch, n);
+    if (!code || !aligned16(code) || n < 0 || sh < 0) return fail(RC_EINVAL, "bad code buffer / pitch%s");
     if (fmt < RC_FMT_U8 || fmt > RC_FMT_F32 || !onehot || !aligned16(onehot)) return fail(RC_EINVAL, "rc_onehot_from_code: dense fmt and aligned buffer required%s");
     if (n == 0) return RC_OK;
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
         const dim3 g((unsigned)((n + kDenseTile - 1) / kDenseTile)), b(kDenseBlock);
-        if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_code_to_dense<T, uint8_t>), g, b, 0, S(stream), code, n, code_pitch, static_cast<uint8_t *>(onehot));
-        else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_code_to_dense<T, uint16_t>), g, b, 0, S(stream), code, n, code_pitch, static_cast<uint16_t *>(onehot));
-        else hipLaunchKernelGGL((k_code_to_dense<T, float>), g, b, 0, S(stream), code, n, code_pitch, static_cast<float *>(onehot));
+        if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_code_to_dense<T, uint8_t>), g, b, 0, S(stream), code, n, code_pitch, sh, static_cast<uint8_t *>(onehot));
+        else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_code_to_dense<T, uint16_t>), g, b, 0, S(stream), code, n, code_pitch, sh, static_cast<uint16_t *>(onehot));
+        else hipLaunchKernelGGL((k_code_to_dense<T, float>), g, b, 0, S(stream), code, n, code_pitch, sh, static_cast<float *>(onehot));
         RC_HIP(hipGetLastError());
         return RC_OK;
     });
@@ -614,7 +652,8 @@ int rc_onehot_from_code(const uint8_t *code, int64_t n, int64_t code_pitch, int 
 
 int rc_expand_children(const uint8_t *in, int64_t n, int64_t pitch_in, int cube_size, uint8_t *children, uint8_t *child_solved,
                        uint8_t *child_code, int64_t pitch_out, void *stream) {
-    if (!in || !aligned16(in) || n < 0 || bad_pitch(pitch_in, n) || bad_pitch(pitch_out, n)) return fail(RC_EINVAL, "rc_expand_children: bad buffer / pitch%s");
+    const int sh_in = tile_shift(pitch_in, n);
+    if (!in || !aligned16(in) || n < 0 || sh_in < 0 || bad_pitch(pitch_out, n)) return fail(RC_EINVAL, "rc_expand_children: bad buffer / pitch%s");
     if (!children && !child_solved && !child_code) return fail(RC_EINVAL, "rc_expand_children: nothing to write%s");
     if ((children && !aligned16(children)) || (child_solved && !aligned16(child_solved)) || (child_code && !aligned16(child_code)))
         return fail(RC_EINVAL, "rc_expand_children: outputs must be 16-byte aligned%s");
@@ -623,7 +662,7 @@ int rc_expand_children(const uint8_t *in, int64_t n, int64_t pitch_in, int cube_
         using T = decltype(t);
         const int V = n >= ((int64_t)1 << 20) ? 2 : 1;
         const int64_t groups = (n + kWave * 4 * V - 1) / (kWave * 4 * V);
-        ExpandArgs a{in, n, pitch_in, children, child_solved, child_code, pitch_out, parts_for(groups, T::A)};
+        ExpandArgs a{in, n, pitch_in, children, child_solved, child_code, pitch_out, parts_for(groups, T::A), sh_in};
         const dim3 g((unsigned)(groups * a.parts)), b(kWave);
         hipStream_t st = S(stream);
         if (V == 2) {

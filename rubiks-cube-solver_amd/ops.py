@@ -3,8 +3,12 @@ operator layer (gym-cube/gym_cube/envs/assets/py333.py:211-246: initState_3, doM
 isSolved_3, getOP_3 + pos_to_state_3) plus the env loops built on it.  Each function
 validates its tensors and forwards raw pointers + the current HIP stream to librubikhip.so.
 
-State layout: uint8 tensor [S, pitch] (structure of arrays: one row per sticker, one column
-per cube), pitch a multiple of 256; only the first n columns are cubes.
+State layout (include/rubikhip.h "State layout"): uint8 tensor [tiles, S, pitch] -- structure of
+arrays in tiles: one row per sticker, one column per cube, `pitch` cubes per tile; cube n sits in
+tile n // pitch, column n % pitch.  A 2-D [S, pitch] tensor is the one-tile case.  Buffers with
+several tiles need a power-of-two pitch >= 1024 (DEFAULT_TILE = 16384 measured best on MI355X).
+Compact code buffers [tiles, SLOTS, pitch] follow the same rule.  Expansion / ADI outputs are
+one-tile ("plain") buffers.
 """
 from __future__ import annotations
 
@@ -24,13 +28,61 @@ def _size(cube_size):
     return N_STICKERS[cube_size], ACTION_DIM[cube_size], N_SLOTS[cube_size]
 
 
+DEFAULT_TILE = 16384
+
+
 def _rows(t, rows, n, what):
-    """t must be a contiguous uint8 device tensor [..., rows, pitch] with pitch >= n, pitch % 16 == 0."""
+    """Plain (one-tile) buffer: contiguous uint8 device tensor [..., rows, pitch], pitch >= n, pitch % 16 == 0."""
     if t.dtype != torch.uint8 or not t.is_cuda or not t.is_contiguous():
         raise RubikHipError(f"{what}: need a contiguous uint8 HIP tensor")
     if t.dim() < 2 or t.shape[-2] != rows or t.shape[-1] < n or t.shape[-1] % 16:
         raise RubikHipError(f"{what}: shape {tuple(t.shape)} is not [..., {rows}, pitch>=n, pitch%16==0]")
     return t.shape[-1]
+
+
+def _tiled(t, rows, n, what):
+    """State / code buffer: [tiles, rows, pitch] (or [rows, pitch] = one tile).  Returns the pitch."""
+    if t.dtype != torch.uint8 or not t.is_cuda or not t.is_contiguous():
+        raise RubikHipError(f"{what}: need a contiguous uint8 HIP tensor")
+    if t.dim() == 2:
+        t = t.unsqueeze(0)
+    if t.dim() != 3 or t.shape[1] != rows:
+        raise RubikHipError(f"{what}: shape {tuple(t.shape)} is not [tiles, {rows}, pitch]")
+    tiles, _, pitch = t.shape
+    if pitch % 16 or tiles * pitch < n:
+        raise RubikHipError(f"{what}: pitch {pitch} x {tiles} tiles cannot hold {n} cubes (pitch % 16 must be 0)")
+    if n > pitch and (pitch < 1024 or pitch & (pitch - 1)):
+        raise RubikHipError(f"{what}: a buffer with several tiles needs a power-of-two pitch >= 1024, got {pitch}")
+    return pitch
+
+
+def _tile_shape(n, pitch):
+    if pitch is None:
+        pitch = _lib.pitch_for(n) if n <= DEFAULT_TILE else DEFAULT_TILE
+    return max(1, -(-n // pitch)), pitch
+
+
+def to_aos(t, n):
+    """[tiles, rows, pitch] (or [rows, pitch]) device buffer -> [n, rows] tensor (one cube per row)."""
+    if t.dim() == 2:
+        t = t.unsqueeze(0)
+    return t.permute(0, 2, 1).reshape(-1, t.shape[1])[:n]
+
+
+def from_aos(a, device, pitch=None):
+    """[n, rows] uint8 (numpy or tensor, host) -> tiled device buffer [tiles, rows, pitch]."""
+    a = torch.as_tensor(a, dtype=torch.uint8)
+    n, rows = a.shape
+    tiles, pitch = _tile_shape(n, pitch)
+    buf = torch.zeros((tiles * pitch, rows), dtype=torch.uint8)
+    buf[:n] = a
+    return buf.reshape(tiles, pitch, rows).permute(0, 2, 1).contiguous().to(device)
+
+
+def alloc_code(n, cube_size, device, pitch=None):
+    _, _, SL = _size(cube_size)
+    tiles, pitch = _tile_shape(n, pitch)
+    return torch.empty((tiles, SL, pitch), dtype=torch.uint8, device=device)
 
 
 def _vec(t, n, dtype, what):
@@ -43,13 +95,13 @@ def _vec(t, n, dtype, what):
 
 def alloc_states(n, cube_size, device, pitch=None):
     S, _, _ = _size(cube_size)
-    pitch = pitch or _lib.pitch_for(n)
-    return torch.empty((S, pitch), dtype=torch.uint8, device=device)
+    tiles, pitch = _tile_shape(n, pitch)
+    return torch.empty((tiles, S, pitch), dtype=torch.uint8, device=device)
 
 
 def fill_solved(st, n, cube_size):
     S, _, _ = _size(cube_size)
-    pitch = _rows(st, S, n, "fill_solved")
+    pitch = _tiled(st, S, n, "fill_solved")
     _lib.init(st.device)
     check(lib().rc_fill_solved(ptr(st), n, pitch, cube_size, stream_ptr(st.device)))
     return st
@@ -63,7 +115,7 @@ def _onehot_args(onehot, fmt, n, cube_size, what):
     if onehot is None:
         raise RubikHipError(f"{what}: fmt needs an output tensor")
     if fmt == FMT_CODE:
-        return onehot, _rows(onehot, N_SLOTS[cube_size], n, what + " code")
+        return onehot, _tiled(onehot, N_SLOTS[cube_size], n, what + " code")
     R, C = STATE_DIM[cube_size]
     if onehot.dtype != _lib.dense_dtype(fmt) or not onehot.is_cuda or not onehot.is_contiguous() or onehot.numel() < n * R * C:
         raise RubikHipError(f"{what}: dense one-hot must be a contiguous {_lib.dense_dtype(fmt)} HIP tensor [n,{R},{C}]")
@@ -73,7 +125,7 @@ def _onehot_args(onehot, fmt, n, cube_size, what):
 def apply_moves(src, dst, actions, n, cube_size, reward=None, done=None, onehot=None, fmt=FMT_NONE):
     """CubeEnv.step for n cubes (cube_env.py:71-111).  dst may be src (in place)."""
     S, _, _ = _size(cube_size)
-    p_in, p_out = _rows(src, S, n, "apply_moves src"), _rows(dst, S, n, "apply_moves dst")
+    p_in, p_out = _tiled(src, S, n, "apply_moves src"), _tiled(dst, S, n, "apply_moves dst")
     _vec(actions, n, torch.uint8, "actions")
     _vec(reward, n, torch.float32, "reward")
     _vec(done, n, torch.uint8, "done")
@@ -87,7 +139,7 @@ def scramble(st, n, cube_size, depth, seed=0, stream_id=0, walk_offset=0, action
              done=None, reward=None):
     """reset()'s scramble loop in place (cube_env.py:65-67); actions_* are [depth, pitch] uint8."""
     S, _, _ = _size(cube_size)
-    pitch = _rows(st, S, n, "scramble")
+    pitch = _tiled(st, S, n, "scramble")
     ap = 0
     for a in (actions_in, actions_out):
         if a is not None:
@@ -101,7 +153,7 @@ def scramble(st, n, cube_size, depth, seed=0, stream_id=0, walk_offset=0, action
 
 def is_solved(st, n, cube_size, done=None, reward=None):
     S, _, _ = _size(cube_size)
-    pitch = _rows(st, S, n, "is_solved")
+    pitch = _tiled(st, S, n, "is_solved")
     _vec(reward, n, torch.float32, "reward")
     _vec(done, n, torch.uint8, "done")
     _lib.init(st.device)
@@ -110,7 +162,7 @@ def is_solved(st, n, cube_size, done=None, reward=None):
 
 def encode(st, n, cube_size, onehot, fmt):
     S, _, _ = _size(cube_size)
-    pitch = _rows(st, S, n, "encode")
+    pitch = _tiled(st, S, n, "encode")
     oh, cp = _onehot_args(onehot, fmt, n, cube_size, "encode")
     _lib.init(st.device)
     check(lib().rc_encode(ptr(st), n, pitch, cube_size, ptr(oh), fmt, cp, stream_ptr(st.device)))
@@ -118,7 +170,7 @@ def encode(st, n, cube_size, onehot, fmt):
 
 def onehot_from_code(code, n, cube_size, onehot):
     _size(cube_size)
-    cp = _rows(code, N_SLOTS[cube_size], n, "onehot_from_code")
+    cp = _tiled(code, N_SLOTS[cube_size], n, "onehot_from_code")
     fmt = _lib.fmt_of(onehot.dtype)
     _onehot_args(onehot, fmt, n, cube_size, "onehot_from_code")
     _lib.init(code.device)
@@ -128,7 +180,7 @@ def onehot_from_code(code, n, cube_size, onehot):
 def expand_children(st, n, cube_size, children=None, child_solved=None, child_code=None):
     """children [A,S,pitch], child_solved [A,pitch], child_code [A,SLOTS,pitch] (same pitch)."""
     S, A, SL = _size(cube_size)
-    p_in = _rows(st, S, n, "expand src")
+    p_in = _tiled(st, S, n, "expand src")
     pitches = set()
     if children is not None:
         pitches.add(_rows(children, S, n, "children"))

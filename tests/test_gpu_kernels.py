@@ -27,17 +27,25 @@ def L():
 
 
 def to_dev(states_aos, pitch=None):
-    """[n,S] numpy -> [S,pitch] device tensor (pad columns hold garbage-free zeros)."""
-    from rubiks_cube_solver_amd import _lib
-    n, S = states_aos.shape
-    pitch = pitch or _lib.pitch_for(n)
-    t = torch.zeros((S, pitch), dtype=torch.uint8)
-    t[:, :n] = torch.from_numpy(np.ascontiguousarray(states_aos.T))
-    return t.cuda()
+    """[n,S] numpy -> tiled device buffer [tiles,S,pitch] (pad columns are zero)."""
+    from rubiks_cube_solver_amd import ops
+    return ops.from_aos(states_aos, "cuda", pitch)
+
+
+def st_host(t, n):
+    """tiled state / code buffer -> [n, rows] numpy."""
+    from rubiks_cube_solver_amd import ops
+    return ops.to_aos(t, n).cpu().numpy()
 
 
 def to_host(t, n):
+    """plain buffer [..., rows, pitch] -> [..., n, rows] numpy."""
     return np.ascontiguousarray(t[..., :n].cpu().numpy().swapaxes(-1, -2))
+
+
+def code_buf(ops, n, cs, like):
+    """zeroed code buffer with the same tiling as the state buffer `like`."""
+    return torch.zeros((like.shape[0], SL_OF[cs], like.shape[2]), dtype=torch.uint8, device="cuda")
 
 
 def random_states(oracle, cs, n, depth, seed):
@@ -74,12 +82,13 @@ def test_library_tables_match_package(L):
 
 
 @pytest.mark.parametrize("cs", CS)
-@pytest.mark.parametrize("n", [1, 3, 4, 63, 257, 1000, 4099])
-def test_fill_and_is_solved(ops, oracle, cs, n):
-    st = ops.alloc_states(n, cs, "cuda")
+@pytest.mark.parametrize("n,pitch", [(1, None), (3, None), (4, 16), (63, None), (257, 1024), (1000, None), (4099, 1024),
+                                     (40000, None), (40000, 2048)])
+def test_fill_and_is_solved(ops, oracle, cs, n, pitch):
+    st = ops.alloc_states(n, cs, "cuda", pitch)
     st.fill_(7)
     ops.fill_solved(st, n, cs)
-    assert (to_host(st, n) == oracle.solved(cs, n)).all()
+    assert (st_host(st, n) == oracle.solved(cs, n)).all()
     done = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
     rew = torch.zeros(n, dtype=torch.float32, device="cuda")
     ops.is_solved(st, n, cs, done, rew)
@@ -87,9 +96,10 @@ def test_fill_and_is_solved(ops, oracle, cs, n):
 
 
 @pytest.mark.parametrize("cs", CS)
-@pytest.mark.parametrize("variant", [1, 2, 3, 11, 12, 13])
-@pytest.mark.parametrize("n", [1, 5, 64, 255, 1021, 16384 + 3])
-def test_apply_moves_vs_oracle(ops, L, oracle, cs, variant, n):
+@pytest.mark.parametrize("variant", [1, 2, 3, 11, 12, 23])
+@pytest.mark.parametrize("n,pitch", [(1, None), (5, None), (64, 64), (255, None), (1021, None), (16384 + 3, None),
+                                     (16384 + 3, 1024), (16384 + 3, 32768)])
+def test_apply_moves_vs_oracle(ops, L, oracle, cs, variant, n, pitch):
     L.lib().rc_set_variant(variant)
     try:
         S, A = S_OF[cs], A_OF[cs]
@@ -101,15 +111,15 @@ def test_apply_moves_vs_oracle(ops, L, oracle, cs, variant, n):
         states[:k] = oracle.solved(cs, k)
         exp_st, exp_code, exp_done, exp_rew = oracle.step(cs, states, acts)
         back = np.array([a ^ 1 for a in acts[:k]], np.uint8)
-        src = to_dev(states)
+        src = to_dev(states, pitch)
         dst = torch.zeros_like(src)
         a_d = torch.from_numpy(acts).cuda()
         rew = torch.zeros(n, dtype=torch.float32, device="cuda")
         done = torch.full((n,), 7, dtype=torch.uint8, device="cuda")
-        code = torch.zeros((SL_OF[cs], src.shape[1]), dtype=torch.uint8, device="cuda")
+        code = code_buf(ops, n, cs, src)
         ops.apply_moves(src, dst, a_d, n, cs, rew, done, code, L.FMT_CODE)
-        assert (to_host(dst, n) == exp_st).all()
-        assert (to_host(code, n) == exp_code).all()
+        assert (st_host(dst, n) == exp_st).all()
+        assert (st_host(code, n) == exp_code).all()
         assert (done.cpu().numpy() == exp_done).all()
         assert (rew.cpu().numpy() == exp_rew).all()
         # second step in place undoes the first k cubes -> solved
@@ -117,7 +127,7 @@ def test_apply_moves_vs_oracle(ops, L, oracle, cs, variant, n):
         acts2[:k] = back
         exp2, _, exp_done2, exp_rew2 = oracle.step(cs, exp_st, acts2)
         ops.apply_moves(dst, dst, torch.from_numpy(acts2).cuda(), n, cs, rew, done)
-        assert (to_host(dst, n) == exp2).all()
+        assert (st_host(dst, n) == exp2).all()
         assert (done.cpu().numpy() == exp_done2).all() and exp_done2[:k].all()
         assert (rew.cpu().numpy() == exp_rew2).all()
         assert L.read_status() == 0
@@ -127,20 +137,20 @@ def test_apply_moves_vs_oracle(ops, L, oracle, cs, variant, n):
 
 @pytest.mark.parametrize("cs", CS)
 @pytest.mark.parametrize("fmt_name", ["U8", "F16", "F32"])
-@pytest.mark.parametrize("n", [1, 6, 1023, 1024, 1025, 5000])
-def test_apply_moves_dense_onehot(ops, L, oracle, cs, fmt_name, n):
+@pytest.mark.parametrize("n,pitch", [(1, None), (6, None), (1023, None), (1024, None), (1025, None), (5000, None), (5000, 1024)])
+def test_apply_moves_dense_onehot(ops, L, oracle, cs, fmt_name, n, pitch):
     fmt = getattr(L, "FMT_" + fmt_name)
     R, C = RC_OF[cs]
     states = random_states(oracle, cs, n, 9, seed=100 + n)
     acts = np.random.default_rng(n).integers(0, A_OF[cs], n, dtype=np.uint8)
     exp_st, exp_code, exp_done, exp_rew = oracle.step(cs, states, acts)
-    src = to_dev(states)
+    src = to_dev(states, pitch)
     dst = torch.zeros_like(src)
     oh = torch.full((n, R, C), 3, dtype=L.dense_dtype(fmt), device="cuda")
     rew = torch.zeros(n, dtype=torch.float32, device="cuda")
     done = torch.zeros(n, dtype=torch.uint8, device="cuda")
     ops.apply_moves(src, dst, torch.from_numpy(acts).cuda(), n, cs, rew, done, oh, fmt)
-    assert (to_host(dst, n) == exp_st).all()
+    assert (st_host(dst, n) == exp_st).all()
     exp_oh = dense_from_code(cs, exp_code)
     _, oracle_oh = oracle.encode(cs, exp_st)
     assert (exp_oh == oracle_oh).all()
@@ -151,9 +161,9 @@ def test_apply_moves_dense_onehot(ops, L, oracle, cs, fmt_name, n):
     oh2 = torch.full_like(oh, 5)
     ops.encode(dst, n, cs, oh2, fmt)
     assert torch.equal(oh, oh2)
-    code = torch.zeros((SL_OF[cs], src.shape[1]), dtype=torch.uint8, device="cuda")
+    code = code_buf(ops, n, cs, src)
     ops.encode(dst, n, cs, code, L.FMT_CODE)
-    assert (to_host(code, n) == exp_code).all()
+    assert (st_host(code, n) == exp_code).all()
     oh3 = torch.full_like(oh, 5)
     ops.onehot_from_code(code, n, cs, oh3)
     assert torch.equal(oh, oh3)
@@ -165,14 +175,14 @@ def test_golden_walks_on_gpu(ops, L, golden):
     W, D = g["actions"].shape
     st = ops.alloc_states(W, 3, "cuda")
     ops.fill_solved(st, W, 3)
-    code = torch.zeros((20, st.shape[1]), dtype=torch.uint8, device="cuda")
+    code = code_buf(ops, W, 3, st)
     rew = torch.zeros(W, dtype=torch.float32, device="cuda")
     done = torch.zeros(W, dtype=torch.uint8, device="cuda")
     acts = torch.from_numpy(np.ascontiguousarray(g["actions"].T)).cuda()
     for d in range(D):
         ops.apply_moves(st, st, acts[d].contiguous(), W, 3, rew, done, code, L.FMT_CODE)
-        assert (to_host(st, W) == g["stickers"][:, d]).all()
-        assert (to_host(code, W) == g["cols"][:, d]).all()
+        assert (st_host(st, W) == g["stickers"][:, d]).all()
+        assert (st_host(code, W) == g["cols"][:, d]).all()
         assert (done.cpu().numpy() == g["done"][:, d]).all()
         assert (rew.cpu().numpy() == g["reward"][:, d]).all()
 
@@ -181,9 +191,9 @@ def test_golden_encode_arbitrary_colourings(ops, L, golden):
     g = golden("encode_333")
     n = len(g["stickers"])
     st = to_dev(g["stickers"])
-    code = torch.zeros((20, st.shape[1]), dtype=torch.uint8, device="cuda")
+    code = code_buf(ops, n, 3, st)
     ops.encode(st, n, 3, code, L.FMT_CODE)
-    assert (to_host(code, n) == g["cols"]).all()
+    assert (st_host(code, n) == g["cols"]).all()
     done = torch.zeros(n, dtype=torch.uint8, device="cuda")
     ops.is_solved(st, n, 3, done)
     assert (done.cpu().numpy() == g["solved"]).all()
@@ -195,13 +205,13 @@ def test_golden_encode_arbitrary_colourings(ops, L, golden):
 
 @pytest.mark.parametrize("cs", CS)
 @pytest.mark.parametrize("n", [1, 37, 512, 4096, 70000])
-def test_expand_children(ops, oracle, cs, n):
+def test_expand_children(ops, L, oracle, cs, n):
     S, A, SL = S_OF[cs], A_OF[cs], SL_OF[cs]
     states = random_states(oracle, cs, n, 20, seed=n)
     states[: max(1, n // 7)] = oracle.step(cs, oracle.solved(cs, max(1, n // 7)), np.arange(max(1, n // 7)) % A)[0]
     ch, cc, cso = oracle.expand(cs, states, threads=4)
     src = to_dev(states)
-    p = src.shape[1]
+    p = L.pitch_for(n)
     children = torch.zeros((A, S, p), dtype=torch.uint8, device="cuda")
     solved = torch.zeros((A, p), dtype=torch.uint8, device="cuda")
     code = torch.zeros((A, SL, p), dtype=torch.uint8, device="cuda")
@@ -214,11 +224,11 @@ def test_expand_children(ops, oracle, cs, n):
     assert torch.equal(solved[:, :n], solved2[:, :n])
 
 
-def test_golden_expand(ops, golden):
+def test_golden_expand(ops, L, golden):
     g = golden("expand_333")
     n = len(g["leaves"])
     src = to_dev(g["leaves"])
-    p = src.shape[1]
+    p = L.pitch_for(n)
     children = torch.zeros((12, 54, p), dtype=torch.uint8, device="cuda")
     solved = torch.zeros((12, p), dtype=torch.uint8, device="cuda")
     code = torch.zeros((12, 20, p), dtype=torch.uint8, device="cuda")
@@ -265,13 +275,13 @@ def test_scramble_matches_adi_and_reset_golden(ops, L, oracle, golden, cs):
     n, depth = 777, 25
     st = ops.alloc_states(n, cs, "cuda")
     ops.fill_solved(st, n, cs)
-    p = st.shape[1]
+    p = L.pitch_for(n)
     a_out = torch.zeros((depth, p), dtype=torch.uint8, device="cuda")
     done = torch.zeros(n, dtype=torch.uint8, device="cuda")
     ops.scramble(st, n, cs, depth, seed=9, stream_id=1, walk_offset=5, actions_out=a_out, done=done)
     exp = oracle.adi(cs, n, depth, seed=9, stream=1, walk0=5, want_children=False)
     assert (a_out[:, :n].cpu().numpy().T == exp["actions"]).all()
-    assert (to_host(st, n) == exp["parents"][:, -1]).all()
+    assert (st_host(st, n) == exp["parents"][:, -1]).all()
     assert (done.cpu().numpy() == oracle.is_solved(cs, exp["parents"][:, -1])).all()
     if cs == 3:  # G4: the reference's reset(seed, k) action draws replayed on the device
         g = golden("reset_333")
@@ -280,10 +290,10 @@ def test_scramble_matches_adi_and_reset_golden(ops, L, oracle, golden, cs):
             k = int(g["ks"][j])
             st = ops.alloc_states(ns, 3, "cuda")
             ops.fill_solved(st, ns, 3)
-            a_in = torch.zeros((k, st.shape[1]), dtype=torch.uint8, device="cuda")
+            a_in = torch.zeros((k, L.pitch_for(ns)), dtype=torch.uint8, device="cuda")
             a_in[:, :ns] = torch.from_numpy(np.ascontiguousarray(g["actions"][:, j, :k].T)).cuda()
             ops.scramble(st, ns, 3, k, actions_in=a_in)
-            assert (to_host(st, ns) == g["stickers"][:, j]).all()
+            assert (st_host(st, ns) == g["stickers"][:, j]).all()
 
 
 def test_bad_action_sets_status(ops, L):
@@ -310,7 +320,9 @@ def test_argument_errors(ops, L):
     with pytest.raises(NotImplementedError):
         ops.alloc_states(10, 4, "cuda")
     with pytest.raises(L.RubikHipError):
-        ops.fill_solved(st[:, :7], 7, 3)            # non-contiguous / bad pitch
+        ops.fill_solved(st[:, :, :7], 7, 3)         # non-contiguous / bad pitch
+    with pytest.raises(L.RubikHipError):
+        ops.fill_solved(torch.zeros((4, 54, 48), dtype=torch.uint8, device="cuda"), 100, 3)  # tiles need pow2 pitch >= 1024
     with pytest.raises(L.RubikHipError):
         ops.apply_moves(st, st, torch.zeros(10, dtype=torch.int64, device="cuda"), 10, 3)
     with pytest.raises(L.RubikHipError):
@@ -318,6 +330,7 @@ def test_argument_errors(ops, L):
     assert L.lib().rc_fill_solved(None, 1, 256, 3, None) == -1
     assert b"rc_fill_solved" in L.lib().rc_last_error()
     assert L.lib().rc_fill_solved(L.ptr(st), 1, 256, 5, None) == -1
+    assert L.lib().rc_fill_solved(L.ptr(st), 2000, 48, 3, None) == -1
 
 
 @pytest.mark.parametrize("cs", CS)
@@ -354,13 +367,14 @@ def test_full_size_properties(ops, L):
     acts = torch.randint(0, 12, (n,), generator=g, device="cuda", dtype=torch.uint8)
     tmp = torch.empty_like(st)
     ops.apply_moves(st, tmp, acts, n, 3)
-    assert not torch.equal(tmp[:, :n], ref[:, :n])
-    assert torch.equal(tmp[:, :n].to(torch.int32).sum(0), ref[:, :n].to(torch.int32).sum(0))  # a move permutes stickers
+    assert st.shape[0] > 1                                         # tiled layout at this size
+    assert not torch.equal(tmp, ref)
+    assert torch.equal(tmp.to(torch.int32).sum(1), ref.to(torch.int32).sum(1))  # a move permutes stickers
     ops.apply_moves(tmp, st, acts ^ 1, n, 3)                      # X then X' = identity
-    assert torch.equal(st[:, :n], ref[:, :n])
+    assert torch.equal(st, ref)
     for _ in range(4):                                             # X^4 = identity
         ops.apply_moves(st, st, acts, n, 3)
-    assert torch.equal(st[:, :n], ref[:, :n])
+    assert torch.equal(st, ref)
     done = torch.zeros(n, dtype=torch.uint8, device="cuda")
     ops.is_solved(st, n, 3, done)
     assert int(done.sum()) < n // 1000

@@ -40,7 +40,7 @@ def main():
         t = timeit(lambda: b.copy_(a))
         out.append(dict(k="torch_copy_54rows", ms=t * 1e3, GBps=2 * a.numel() / t / 1e9))
     if "step" in which:
-        for var in (1, 2, 3, 11, 12, 13):
+        for var in (1, 2, 3, 11, 12, 13, 21, 22):
             L.rc_set_variant(var)
             buf = [a, b]
             def f():
@@ -59,7 +59,7 @@ def main():
             out.append(dict(k=f"step_inplace_v{var}", ms=t * 1e3, Gsteps=n / t / 1e9, GBps=110 * n / t / 1e9))
         L.rc_set_variant(0)
     if "code" in which:
-        code = torch.empty((20, a.shape[1]), dtype=torch.uint8, device="cuda")
+        code = ops.alloc_code(n, 3, "cuda")
         for var in (1, 2, 3):
             L.rc_set_variant(var)
             buf = [a, b]
@@ -93,7 +93,9 @@ def main():
     if "expand" in which:
         for m in (4096, 1 << 20):
             p = _lib.pitch_for(m)
-            src = a[:, :p].contiguous()
+            src = ops.alloc_states(m, 3, "cuda")
+            ops.fill_solved(src, m, 3)
+            ops.scramble(src, m, 3, 20, seed=5)
             ch = torch.empty((12, 54, p), dtype=torch.uint8, device="cuda")
             cs = torch.empty((12, p), dtype=torch.uint8, device="cuda")
             t = timeit(lambda: ops.expand_children(src, m, 3, ch, cs), iters=20)

@@ -1,0 +1,219 @@
+"""CubeEnv / make_env: the reference's batch-1 env surface on top of the HIP library.
+
+Mirrors gym-cube/gym_cube/envs/cube_env.py:12-252 and env.py:3-5 -- same method names, argument
+meaning, return types and error behaviour -- so train.py / mcts.py / test.py style callers run
+unchanged, while every cube operation (move, solved test, one-hot, child expansion, ADI walks)
+executes in librubikhip.so on the GPU.  There is no CPU implementation behind this class.
+
+Differences that are deliberate and documented in DESIGN.md:
+  * `device` keeps the reference's meaning (where model tensors are created, cube_env.py:240,249);
+    the cubes themselves live on `compute_device` (default: the current HIP device);
+  * rendering (render / close_render / save_video, cube_env.py:113-130,254-275) is out of scope.
+"""
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .tables import ACTION_NAMES, get_env_config, get_tables
+
+
+class CubeEnv:
+    metadata = {"render_modes": ["human", "rgb_array"]}
+
+    def __init__(self, device, cube_size=2, compute_device=None, _backend=None):
+        """device: torch device for model tensors (e.g. torch.device('cpu:0')); cube_size: 2 or 3."""
+        self.cube_size = cube_size
+        self.device = device
+        self.action_to_sim_action = {  # cube_env.py:24-28
+            2: list(ACTION_NAMES[2]),
+            3: list(ACTION_NAMES[3]),
+            "render": [["U", 1], ["U", -1], ["F", 1], ["F", -1], ["R", 1], ["R", -1],
+                       ["D", 1], ["D", -1], ["B", 1], ["B", -1], ["L", 1], ["L", -1]],
+        }
+        self.show_cube = False
+        if cube_size not in (2, 3):
+            raise NotImplementedError  # get_env_config / init_state, cube_env.py:30,44
+        self.state_dim, self.action_dim = get_env_config(cube_size)
+        if _backend is None:
+            from .vec_env import VecCubeEnv
+            if compute_device is None:
+                d = torch.device(device) if not isinstance(device, torch.device) else device
+                compute_device = d if d.type == "cuda" else "cuda"
+            _backend = VecCubeEnv(1, compute_device, cube_size, obs="onehot", onehot_dtype=torch.uint8)
+        self._vec = _backend
+        self._sim_cache = None
+        self._cube_cache = None
+        self.init_state()
+
+    # ------------------------------------------------------------------ state attributes
+    @property
+    def sim_cube(self):
+        """Sticker vector, int64 ndarray [54] | [24] (py333.py:212-218 dtype)."""
+        if self._sim_cache is None:
+            self._sim_cache = self._vec.sim_cube[0].cpu().numpy().astype(np.int64)
+        return self._sim_cache
+
+    @sim_cube.setter
+    def sim_cube(self, value):
+        v = np.asarray(value)
+        self._vec.set_sim_cube(v.reshape(1, -1).astype(np.uint8))
+        self._sim_cache = v.astype(np.int64).copy()
+        self._cube_cache = None
+
+    @property
+    def cube(self):
+        """One-hot state: int64 [20,24] (py333.py:238) or float64 [7,21] (cube_env.py:143)."""
+        if self._cube_cache is None:
+            self._cube_cache = self._typed(self._vec.sim_state_to_state(dtype=torch.uint8)[0])
+        return self._cube_cache
+
+    def _typed(self, onehot_u8):
+        a = onehot_u8.cpu().numpy()
+        return a.astype(np.int64) if self.cube_size == 3 else a.astype(np.float64)
+
+    # ------------------------------------------------------------------ reference surface
+    def init_state(self):
+        """Initialize state (cube_env.py:33-48)."""
+        if self.cube_size not in (2, 3):
+            raise NotImplementedError
+        obs = self._vec.init_state()
+        self._sim_cache = None
+        self._cube_cache = self._typed(obs[0])
+
+    def reset(self, seed=None, scramble_count=2):
+        """Reset to a randomly scrambled cube (cube_env.py:50-69): the global legacy numpy RNG is
+        saved, optionally seeded, used for `randint(action_dim, size=scramble_count)` and restored."""
+        self.init_state()
+        origin_state = np.random.get_state()
+        if seed is not None:
+            np.random.seed(seed)
+        action_sequence = np.random.randint(self.action_dim, size=scramble_count)
+        np.random.set_state(origin_state)
+        if len(action_sequence) == 0:
+            raise UnboundLocalError("local variable 'state' referenced before assignment")  # cube_env.py:69
+        obs = self._vec.reset(actions=action_sequence.reshape(1, -1).astype(np.uint8), scramble_count=len(action_sequence))
+        self._sim_cache = None
+        self._cube_cache = self._typed(obs[0])
+        return self._cube_cache
+
+    def step(self, action):
+        """action: int 0..A-1 in the order U,U',F,F',R,R'[,D,D',B,B',L,L'].
+        Returns (state ndarray, reward +1.0/-1.0, done bool, {}) -- cube_env.py:71-111."""
+        if self.cube_size not in (2, 3):
+            raise NotImplementedError
+        names = self.action_to_sim_action[self.cube_size]
+        sim_action = names[action]  # IndexError / TypeError exactly like the reference's list lookup
+        idx = names.index(sim_action)  # moveInds, py333.py:41-44,221
+        obs, reward, done, _ = self._vec.step(torch.tensor([idx], dtype=torch.uint8))
+        self._sim_cache = None
+        self._cube_cache = self._typed(obs[0])
+        solved = bool(done[0].item())
+        return self._cube_cache, (1.0 if solved else -1.0), solved, {}
+
+    def sim_state_to_state(self, sim_state):
+        """One-hot of an arbitrary sticker vector (cube_env.py:132-152)."""
+        if self.cube_size not in (2, 3):
+            raise NotImplementedError
+        st = ops.from_aos(np.asarray(sim_state).reshape(1, -1).astype(np.uint8), self._vec.device)
+        out = torch.empty((1, *self.state_dim), dtype=torch.uint8, device=self._vec.device)
+        ops.encode(st, 1, self.cube_size, out, _lib.FMT_U8)
+        return self._typed(out[0])
+
+    def state_to_sim_state(self, state):
+        """One-hot -> stickers.  2x2x2 only (cube_env.py:154-175; unused by the reference's callers);
+        a host-side table inversion, not part of the hot path."""
+        if self.cube_size == 3:
+            raise NotImplementedError
+        if self.cube_size != 2:
+            raise NotImplementedError
+        t = get_tables(2)
+        stickers = np.array(t.solved, dtype=np.int64)
+        for cubelet, row in enumerate(np.asarray(state)):
+            col = int(np.where(row == 1.0)[0][0])
+            position, ori = col // 3, col % 3
+            colours = [int(t.solved[i]) for i in t.corner_defs[cubelet]]
+            rot = colours[-ori:] + colours[:-ori] if ori else colours
+            for k in range(3):
+                stickers[t.corner_defs[position][k]] = rot[k]
+        return stickers
+
+    def get_random_samples(self, replay_buffer, model, sample_scramble_count, sample_cube_count, temperature):
+        """ADI samples into replay_buffer (cube_env.py:177-194): for each of sample_cube_count cubes the
+        moves come from np.random.randint(action_dim, size=sample_scramble_count) on the global legacy
+        RNG, exactly as the reference draws them; walks, expansion, one-hots and targets run on the GPU."""
+        from .adi import adi_samples, samples_to_dicts
+
+        if sample_cube_count <= 0:
+            return
+        actions = np.stack([np.random.randint(self.action_dim, size=sample_scramble_count)
+                            for _ in range(sample_cube_count)]).astype(np.uint8)
+        if sample_scramble_count > 0:
+            res = adi_samples(model, self.cube_size, sample_cube_count, sample_scramble_count, temperature,
+                              device=self._vec.device, model_device=self.device, actions=actions, want_state_dense=True)
+            for sample in samples_to_dicts(res, self.cube_size):
+                replay_buffer.append(sample)
+            # the env is left on the last walk's final state, as in the reference
+            self._vec.reset(actions=actions[-1:], scramble_count=sample_scramble_count)
+        else:
+            self._vec.init_state()
+        self._sim_cache = None
+        self._cube_cache = None
+
+    def get_target_value(self, model, scramble_count, temperature):
+        """(target_value, target_policy, error) of the CURRENT state (cube_env.py:196-252)."""
+        if self.cube_size not in (2, 3):
+            raise NotImplementedError
+        ex = self._vec.expand(codes=True)
+        solved = ex["child_solved"][:, 0].cpu().numpy().astype(bool)
+        reward = -1.0
+        if solved.any():  # lowest solved action wins, value exactly 1.0 (cube_env.py:229-232)
+            reward, target_value, target_policy = 1.0, 1.0, int(np.argmax(solved))
+        if reward != 1.0:
+            A = self.action_dim
+            dense = torch.empty((A, *self.state_dim), dtype=torch.float32, device=self._vec.device)
+            for a in range(A):
+                ops.onehot_from_code(ex["child_code"][a], 1, self.cube_size, dense[a:a + 1])
+            next_state_tensor = dense.to(self.device)
+            reward_tensor = torch.tensor([-1.0] * A, device=self.device)
+            with torch.no_grad():
+                next_value, _ = model(next_state_tensor)
+                value = next_value.squeeze(dim=-1).detach() + reward_tensor
+            target_value, target_policy = torch.max(value, -1, keepdim=True)
+            target_value, target_policy = target_value.item(), target_policy.item()
+        weight = scramble_count ** (-1 * temperature)
+        with torch.no_grad():
+            state_tensor = torch.tensor(self.cube, device=self.device).float()
+            value, _ = model(state_tensor)
+            error = abs(value.detach().item() - target_value) * weight
+        return target_value, target_policy, error
+
+    # ------------------------------------------------------------------ out of scope: rendering
+    def render(self, mode=None):
+        raise NotImplementedError("rendering (cube_env.py:113-122) is out of scope of the MI355X env path")
+
+    def close_render(self):
+        raise NotImplementedError("rendering (cube_env.py:124-130) is out of scope of the MI355X env path")
+
+    def save_video(self, *args, **kwargs):
+        raise NotImplementedError("rendering (cube_env.py:254-275) is out of scope of the MI355X env path")
+
+    # mcts.py:37,96,101 deep-copies the env
+    def __deepcopy__(self, memo):
+        other = object.__new__(CubeEnv)
+        for k, v in self.__dict__.items():
+            if k == "_vec":
+                other._vec = self._vec.clone()
+            elif k in ("device",):
+                other.device = self.device
+            else:
+                setattr(other, k, copy.deepcopy(v, memo))
+        return other
+
+
+def make_env(device, cube_size):
+    """env.py:3-5: gym.make('cube-v0', cube_size=cube_size, device=device) -> CubeEnv."""
+    return CubeEnv(device=device, cube_size=cube_size)

@@ -1,0 +1,203 @@
+"""Env surface on the GPU: VecCubeEnv and the CubeEnv facade against the oracle env and the
+reference's golden vectors (reset KATs, ADI samples with the stub model).  GPU only."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def stub_model(g, device="cpu"):
+    w, b = torch.tensor(g["w"], device=device), torch.tensor(g["b"], device=device)
+
+    def model(x):
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+        return (x.reshape(x.shape[0], -1) @ w + b).unsqueeze(-1), torch.zeros(x.shape[0], 12, device=x.device)
+    return model
+
+
+@pytest.fixture(scope="module")
+def mod():
+    import rubiks_cube_solver_amd as r
+    return r
+
+
+def test_make_env_facade_matches_oracle_env(mod, golden):
+    from oracle.oracle_np import OracleCubeEnv
+    env = mod.make_env(torch.device("cpu"), 3)
+    ref = OracleCubeEnv(None, 3)
+    assert env.state_dim == ref.state_dim and env.action_dim == ref.action_dim
+    assert (env.sim_cube == ref.sim_cube).all() and (env.cube == ref.cube).all() and env.cube.dtype == ref.cube.dtype
+    rng = np.random.default_rng(0)
+    for _ in range(60):
+        a = int(rng.integers(0, 12))
+        s, r, d, info = env.step(a)
+        s2, r2, d2, _ = ref.step(a)
+        assert (s == s2).all() and s.dtype == s2.dtype and r == r2 and d == d2 and info == {}
+        assert (env.sim_cube == ref.sim_cube).all()
+    g = golden("reset_333")
+    for i, seed in enumerate(g["seeds"][:4]):
+        for j in (0, 6, 29):
+            s = env.reset(seed=int(seed), scramble_count=int(g["ks"][j]))
+            assert (env.sim_cube == g["stickers"][i, j]).all() and (np.argmax(s, 1) == g["cols"][i, j]).all()
+    arb = golden("encode_333")
+    for k in range(5):
+        oh = env.sim_state_to_state(arb["stickers"][k])
+        assert (np.argmax(oh, 1) == arb["cols"][k]).all() and oh.dtype == np.int64
+    with pytest.raises(IndexError):
+        env.step(12)
+    with pytest.raises(UnboundLocalError):
+        env.reset(seed=0, scramble_count=0)
+
+
+def test_facade_222_and_deepcopy(mod):
+    from oracle.oracle_np import OracleCubeEnv
+    env, ref = mod.make_env(torch.device("cpu"), 2), OracleCubeEnv(None, 2)
+    for a in (0, 3, 4, 1, 2, 5, 5, 0):
+        s, r, d, _ = env.step(a)
+        s2, r2, d2, _ = ref.step(a)
+        assert (s == s2).all() and s.dtype == np.float64 and (r, d) == (r2, d2)
+    assert (env.reset(seed=4, scramble_count=20) == ref.reset(seed=4, scramble_count=20)).all()
+    snap = env.sim_cube.copy()
+    other = copy.deepcopy(env)
+    env.step(1)
+    assert (other.sim_cube == snap).all() and not (env.sim_cube == snap).all()
+    other.step(1)
+    assert (other.sim_cube == env.sim_cube).all()
+    assert (env.state_to_sim_state(env.cube) == env.sim_cube).all()
+
+
+def test_get_target_value_matches_reference_golden(mod, golden):
+    g = golden("adi_333")
+    model = stub_model(g)
+    env = mod.make_env(torch.device("cpu"), 3)
+    T = float(g["temperature"])
+    for c in range(6):
+        env.init_state()
+        for d in range(30):
+            env.step(int(g["actions"][c, d]))
+            tv, tp, err = env.get_target_value(model, d + 1, T)
+            assert tp == g["target_policy"][c, d]
+            assert tv == pytest.approx(g["target_value"][c, d], abs=1e-6)
+            assert err == pytest.approx(g["error"][c, d], abs=1e-6)
+            assert isinstance(tv, float) and isinstance(tp, int)
+
+
+def test_get_random_samples_matches_reference_golden(mod, golden):
+    """Same global numpy seed as the golden run -> the same samples, in the same order."""
+    g = golden("adi_333")
+    n = g["actions"].shape[0]
+    env = mod.make_env(torch.device("cpu"), 3)
+    buf = []
+    np.random.seed(int(g["seed"]))
+    env.get_random_samples(buf, stub_model(g), 30, n, float(g["temperature"]))
+    assert len(buf) == n * 30
+    after = np.random.get_state()[1].copy()
+    np.random.seed(int(g["seed"]))
+    for _ in range(n):
+        np.random.randint(12, size=30)
+    assert (np.random.get_state()[1] == after).all()             # consumed exactly the reference's draws
+    tv_ok = 0
+    for i, smp in enumerate(buf):
+        c, d = divmod(i, 30)
+        assert set(smp) == {"state", "target_value", "target_policy", "scramble_count", "error"}
+        assert smp["state"].shape == (20, 24) and smp["state"].dtype == np.int64
+        assert (np.argmax(smp["state"], 1) == g["cols"][c, d]).all() and (smp["state"].sum(1) == 1).all()
+        assert smp["scramble_count"] == d + 1
+        assert smp["target_value"] == pytest.approx(g["target_value"][c, d], abs=1e-5)
+        assert smp["error"] == pytest.approx(g["error"][c, d], abs=1e-5)
+        tv_ok += smp["target_policy"] == g["target_policy"][c, d]
+    assert tv_ok >= len(buf) - 2                                  # arg-max ties within float noise only
+    assert all(b["target_value"] == 1.0 for b in buf[::30])      # depth 1: the inverse move solves
+    assert (env.sim_cube == _final_state(g)).all()
+
+
+def _final_state(g):
+    from oracle.oracle_np import OracleCubeEnv
+    ref = OracleCubeEnv(None, 3)
+    for a in g["actions"][-1]:
+        ref.step(int(a))
+    return ref.sim_cube
+
+
+def test_adi_samples_device_rng_and_gpu_model(mod, oracle, golden):
+    from rubiks_cube_solver_amd.adi import adi_samples
+    g = golden("adi_333")
+    model = stub_model(g, "cuda")
+    W, D = 700, 9
+    res = adi_samples(model, 3, W, D, 0.3, device="cuda", seed=11, stream_id=2, dense_budget_bytes=13 * 1920 * 256,
+                      want_state_dense=True)
+    exp = oracle.adi(3, W, D, seed=11, stream=2, want_children=False)
+    assert (res["actions"].cpu().numpy() == exp["actions"]).all()
+    assert (res["state_code"].cpu().numpy() == exp["parent_code"]).all()
+    assert (res["state"].argmax(-1).cpu().numpy() == exp["parent_code"]).all()
+    w = g["w"].reshape(20, 24).astype(np.float64)
+    v_child = w[np.arange(20), exp["child_code"].astype(np.int64)].sum(-1) + float(g["b"]) - 1.0   # [W, D, 12]
+    solved = exp["child_solved"].astype(bool)
+    tv = np.where(solved.any(-1), 1.0, v_child.max(-1))
+    assert np.allclose(res["target_value"].cpu().numpy(), tv, atol=1e-5)
+    tp = np.where(solved.any(-1), np.argmax(solved, -1), np.argmax(v_child, -1))
+    assert (res["target_policy"].cpu().numpy() == tp).mean() > 0.995
+    v_par = w[np.arange(20), exp["parent_code"].astype(np.int64)].sum(-1) + float(g["b"])
+    err = np.abs(v_par - tv) * np.arange(1, D + 1, dtype=np.float64)[None, :] ** -0.3
+    assert np.allclose(res["error"].cpu().numpy(), err, atol=1e-5)
+    assert (res["scramble_count"][0].cpu().numpy() == np.arange(1, D + 1)).all()
+
+
+@pytest.mark.parametrize("cs", [3, 2])
+@pytest.mark.parametrize("obs", ["onehot", "code", None])
+def test_vec_env_vs_oracle(mod, oracle, cs, obs):
+    n = 20000
+    A = 12 if cs == 3 else 6
+    env = mod.VecCubeEnv(n, "cuda", cs, obs=obs, onehot_dtype=torch.float16, seed=5, stream_id=1)
+    assert env.stickers.shape[0] > 1                                                   # tiled buffer
+    assert (env.sim_cube.cpu().numpy() == oracle.solved(cs, n)).all()
+    o = env.reset(scramble_count=15)
+    exp = oracle.adi(cs, n, 15, seed=5, stream=1, walk0=n, want_children=False)["parents"][:, -1]
+    assert (env.sim_cube.cpu().numpy() == exp).all()
+    acts = np.random.default_rng(1).integers(0, A, n, dtype=np.uint8)
+    o, r, d, info = env.step(acts)
+    e_st, e_code, e_done, e_rew = oracle.step(cs, exp, acts)
+    assert (env.sim_cube.cpu().numpy() == e_st).all() and info == {}
+    assert (r.cpu().numpy() == e_rew).all() and (d.cpu().numpy() == e_done).all()
+    if obs == "onehot":
+        assert o.dtype == torch.float16 and tuple(o.shape) == (n, *env.state_dim)
+        _, e_oh = oracle.encode(cs, e_st)
+        assert (o.cpu().numpy() == e_oh.astype(np.float16)).all()
+    elif obs == "code":
+        from rubiks_cube_solver_amd import ops
+        assert (ops.to_aos(o, n).cpu().numpy() == e_code).all()
+    else:
+        assert o is None
+    ex = env.expand(children=True)
+    ch, cc, cs_ = oracle.expand(cs, e_st, threads=4)
+    assert (ex["child_solved"][:, :n].cpu().numpy().T == cs_).all()
+    assert (ex["child_code"][..., :n].cpu().numpy().transpose(2, 0, 1) == cc).all()
+    assert (ex["children"][..., :n].cpu().numpy().transpose(2, 0, 1) == ch).all()
+    with pytest.raises(IndexError):
+        env.step(np.full(n, A))
+    bad = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    bad[17] = A
+    env.step(bad)                                                                      # device path cannot raise...
+    with pytest.raises(IndexError):
+        env.check_actions()                                                            # ...the status word does
+    clone = copy.deepcopy(env)
+    env.init_state()
+    assert bool(env.is_solved().all()) and not bool(clone.is_solved().all())
+
+
+def test_vec_env_seeded_reset_is_reference_reset(mod, golden):
+    g = golden("reset_333")
+    seeds = [int(s) for s in g["seeds"]]
+    env = mod.VecCubeEnv(len(seeds), "cuda", 3, obs="code")
+    np.random.seed(99)
+    before = np.random.get_state()[1].copy()
+    for j in (0, 13, 29):
+        env.reset(seeds=seeds, scramble_count=int(g["ks"][j]))
+        assert (env.sim_cube.cpu().numpy() == g["stickers"][:, j]).all()
+    assert (np.random.get_state()[1] == before).all()
+    with pytest.raises(UnboundLocalError):
+        env.reset(scramble_count=0)

@@ -1,0 +1,264 @@
+"""Host-side logic on CPU: tables, the C-ABI surface, CubeEnv's Python semantics (with a test-only
+oracle backend), sharding helpers incl. a world_size-2 gloo run.  No GPU compute is called."""
+import copy
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ----------------------------------------------------------------------------- tables
+def test_tables_match_reference_golden(golden):
+    import rubiks_cube_solver_amd as r
+    g, t = golden("tables_333"), r.get_tables(3)
+    assert (t.perm == g["moveDefs"]).all()                      # derived from geometry == reference table
+    assert (t.corner_defs == g["corner_pieceDefs"]).all() and (t.edge_defs == g["edge_pieceDefs"]).all()
+    assert (t.corner_lut == g["corner_pieceInds"]).all() and (t.edge_lut == g["edge_pieceInds"]).all()
+    assert (t.solved == g["initState"]).all()
+    assert list(t.action_names) == list(g["action_names"])
+    assert list(t.state_dim) == list(g["state_dim"]) and t.n_actions == int(g["action_dim"])
+    assert (t.corner_code[:62] == g["corner_pieceInds"][:, 0] * 3 + g["corner_pieceInds"][:, 1]).all()
+    assert (t.edge_code[:55] == g["edge_pieceInds"][:, 0] * 2 + g["edge_pieceInds"][:, 1]).all()
+    assert not t.corner_code[62:].any() and not t.edge_code[55:].any()
+
+
+def test_tables_222_match_oracle_py222():
+    import rubiks_cube_solver_amd as r
+    from oracle.oracle_np import tables_222
+    t, o = r.get_tables(2), tables_222()
+    assert (t.perm == o["perm"]).all() and (t.corner_defs == o["corner_defs"]).all()
+    assert (t.corner_lut == o["corner_lut"]).all()
+    assert r.get_env_config(2) == ([7, 21], 6) and r.get_env_config(3) == ([20, 24], 12)
+    with pytest.raises(NotImplementedError):
+        r.get_env_config(4)
+
+
+def test_move_group_properties():
+    import rubiks_cube_solver_amd as r
+    for cs in (2, 3):
+        p = r.get_tables(cs).perm.astype(int)
+        S = p.shape[1]
+        ident = np.arange(S)
+        for a in range(0, len(p), 2):
+            assert (p[a][p[a + 1]] == ident).all()              # X' undoes X
+            q = ident
+            for _ in range(4):
+                q = q[p[a]]
+            assert (q == ident).all()                           # order 4
+            assert (p[a] != ident).sum() == (20 if cs == 3 else 12)
+        s = ident
+        for _ in range(6):                                      # (R U R' U')^6 = identity
+            for a in (4, 0, 5, 1):
+                s = s[p[a]]
+        assert (s == ident).all()
+    p3 = r.get_tables(3).perm.astype(int)
+    assert all((p3[a][[4, 13, 22, 31, 40, 49]] == [4, 13, 22, 31, 40, 49]).all() for a in range(12))  # centres fixed
+    assert (p3[0][p3[6]] == p3[6][p3[0]]).all()                 # opposite faces commute (U, D)
+
+
+def test_generated_header_is_current():
+    assert subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_tables.py"), "--check"]).returncode == 0
+
+
+# ------------------------------------------------------------------------------ C ABI
+def test_abi_exports_every_declared_symbol():
+    from rubiks_cube_solver_amd import _lib
+    L = _lib.lib()                                              # loads without a GPU
+    header = open(os.path.join(ROOT, "include", "rubikhip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char \*)\s*(rc_\w+)\(", header, re.M))
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.rc_version() >= 100
+    assert L.rc_last_error() == b"" or isinstance(L.rc_last_error(), bytes)
+
+
+def test_abi_tables_equal_package_tables():
+    import rubiks_cube_solver_amd as r
+    from rubiks_cube_solver_amd import _lib
+    for cs in (2, 3):
+        t, p = _lib.get_tables(cs), r.get_tables(cs)
+        assert (t["perm"] == p.perm).all() and (t["corner_code"] == p.corner_code).all()
+        assert (t["edge_code"] == p.edge_code).all() and (t["corner_defs"] == p.corner_defs).all()
+        assert t["dims"][:2] == (p.n_stickers, p.n_actions)
+    assert _lib.lib().rc_get_tables(4, None, None, None, None, None, None, None) == -1
+    assert b"cube_size" in _lib.lib().rc_last_error()
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Compute entry points refuse host tensors / a missing device instead of falling back."""
+    from rubiks_cube_solver_amd import _lib, ops
+    from rubiks_cube_solver_amd.vec_env import VecCubeEnv
+    with pytest.raises(_lib.RubikHipError):
+        ops.fill_solved(torch.zeros((54, 256), dtype=torch.uint8), 10, 3)
+    with pytest.raises(_lib.RubikHipError):
+        VecCubeEnv(4, "cpu", 3)
+    src = open(os.path.join(ROOT, "rubiks-cube-solver_amd", "ops.py")).read()
+    assert "oracle" not in src
+    for f in os.listdir(os.path.join(ROOT, "rubiks-cube-solver_amd")):
+        if f.endswith(".py"):
+            txt = open(os.path.join(ROOT, "rubiks-cube-solver_amd", f)).read()
+            assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_tile_helpers():
+    from rubiks_cube_solver_amd import ops
+    for n, pitch in ((10, None), (5000, 1024), (40000, None), (16384, None)):
+        a = np.random.default_rng(n).integers(0, 6, (n, 54), dtype=np.uint8)
+        t = ops.from_aos(a, "cpu", pitch)
+        assert t.dim() == 3 and t.shape[1] == 54 and t.shape[0] * t.shape[2] >= n
+        assert (ops.to_aos(t, n).numpy() == a).all()
+        if t.shape[0] > 1:
+            k = t.shape[2]
+            assert (t[1, :, 0].numpy() == a[k]).all()           # cube `pitch` opens tile 1
+
+
+# ---------------------------------------------------- CubeEnv host semantics (oracle-backed, CPU)
+def _env(cs):
+    from rubiks_cube_solver_amd.cube_env import CubeEnv
+    from tests.fake_backend import OracleBackend
+    return CubeEnv(torch.device("cpu"), cube_size=cs, _backend=OracleBackend(cs))
+
+
+def test_cube_env_surface_and_types(golden):
+    env = _env(3)
+    assert env.state_dim == [20, 24] and env.action_dim == 12 and env.cube_size == 3 and env.show_cube is False
+    assert env.action_to_sim_action[3] == ["U", "U'", "F", "F'", "R", "R'", "D", "D'", "B", "B'", "L", "L'"]
+    assert env.action_to_sim_action[2] == ["U", "U'", "F", "F'", "R", "R'"]
+    assert env.sim_cube.dtype == np.int64 and env.sim_cube.tolist() == sum([[c] * 9 for c in range(6)], [])
+    s, r, d, info = env.step(0)
+    assert s.shape == (20, 24) and s.dtype == np.int64 and isinstance(r, float) and isinstance(d, bool) and info == {}
+    assert (r, d) == (-1.0, False) and env.step(1)[1:3] == (1.0, True)          # KAT-C
+    assert env.step(-1)[0] is not None                                            # list indexing: -1 = L'
+    for bad in (12, 99, -13):
+        with pytest.raises(IndexError):
+            env.step(bad)
+    with pytest.raises(TypeError):
+        env.step("U")
+    g = golden("walks_333")
+    env.init_state()
+    for d_ in range(30):
+        s, r, dn, _ = env.step(int(g["actions"][3, d_]))
+        assert (env.sim_cube == g["stickers"][3, d_]).all() and (np.argmax(s, 1) == g["cols"][3, d_]).all()
+        assert (env.cube == s).all()
+    e2 = _env(2)
+    s2, _, _, _ = e2.step(2)
+    assert s2.shape == (7, 21) and s2.dtype == np.float64 and e2.state_dim == [7, 21] and e2.action_dim == 6
+    with pytest.raises(IndexError):
+        e2.step(6)
+    from rubiks_cube_solver_amd.cube_env import CubeEnv
+    with pytest.raises(NotImplementedError):
+        CubeEnv(torch.device("cpu"), cube_size=4, _backend=object())
+
+
+def test_cube_env_reset_matches_reference_rng(golden):
+    g = golden("reset_333")
+    env = _env(3)
+    np.random.seed(31337)
+    before = np.random.get_state()[1].copy()
+    for i, seed in enumerate(g["seeds"]):
+        for j in (0, 1, 9, 29):
+            s = env.reset(seed=int(seed), scramble_count=int(g["ks"][j]))
+            assert (env.sim_cube == g["stickers"][i, j]).all() and (np.argmax(s, 1) == g["cols"][i, j]).all()
+    assert (np.random.get_state()[1] == before).all()                             # cube_env.py:62,68
+    a = env.reset(scramble_count=7).copy()                                        # unseeded: draws, then restores
+    assert (env.reset(scramble_count=7) == a).all()
+    with pytest.raises(UnboundLocalError):
+        env.reset(seed=1, scramble_count=0)
+    s = env.reset(seed=10, scramble_count=30)                                     # KAT-B
+    assert "".join(map(str, env.sim_cube)) == "503401005122111541220425001153533522404445432413352330"
+
+
+def test_cube_env_deepcopy_and_assignment():
+    env = _env(3)
+    env.reset(seed=5, scramble_count=11)
+    snap = env.sim_cube.copy()
+    other = copy.deepcopy(env)                                                    # mcts.py:37,96,101
+    env.step(3)
+    assert (other.sim_cube == snap).all() and not (env.sim_cube == snap).all()
+    env.sim_cube = snap                                                           # callers may restore a state
+    assert (env.sim_cube == snap).all() and (env.cube == other.cube).all()
+    for fn in (env.render, env.close_render, env.save_video):
+        with pytest.raises(NotImplementedError):
+            fn()
+    e2 = _env(2)
+    e2.reset(seed=2, scramble_count=9)
+    assert (e2.state_to_sim_state(e2.cube) == e2.sim_cube).all()
+    with pytest.raises(NotImplementedError):
+        env.state_to_sim_state(env.cube)
+
+
+def test_make_env_needs_gpu():
+    from rubiks_cube_solver_amd import _lib
+    from rubiks_cube_solver_amd.cube_env import make_env
+    if not torch.cuda.is_available():
+        with pytest.raises((_lib.RubikHipError, RuntimeError, AssertionError)):
+            make_env(torch.device("cpu"), 3)
+
+
+def test_legacy_scramble_actions(golden):
+    from rubiks_cube_solver_amd.vec_env import legacy_scramble_actions
+    g = golden("reset_333")
+    np.random.seed(1)
+    before = np.random.get_state()[1].copy()
+    a = legacy_scramble_actions(g["seeds"], 30, 12)
+    assert (a == g["actions"][:, 29, :]).all() and (np.random.get_state()[1] == before).all()
+    assert legacy_scramble_actions([0], 5, 12).tolist() == [[5, 0, 3, 11, 3]]
+
+
+# -------------------------------------------------------------------------- sharding
+def test_shard_partitions():
+    from rubiks_cube_solver_amd import dist as d
+    for n in (0, 1, 7, 8, 100_000, (1 << 23) + 5):
+        for ws in (1, 2, 3, 8):
+            parts = [d.shard(n, r, ws) for r in range(ws)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(ws - 1))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1
+    assert len({d.rng_stream(r) for r in range(8)}) == 8
+
+
+_GLOO_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["RC_ROOT"])
+import numpy as np
+from rubiks_cube_solver_amd import dist as d
+from oracle.oracle_np import Oracle
+rank, ws, local = d.init(backend="gloo")
+assert ws == 2
+lo, hi = d.shard(1001, rank, ws)
+orc = Oracle()
+out = orc.adi(3, hi - lo, 6, seed=77, stream=d.rng_stream(rank), walk0=0, want_children=False)   # rank-local walks, own stream
+d.barrier()
+tot, = d.reduce_scalars([float(hi - lo)], op="sum")
+mx, = d.reduce_scalars([float(rank + 1) * 0.5], op="max")
+json.dump({"rank": rank, "lo": lo, "hi": hi, "total": tot, "max": mx,
+           "first_actions": out["actions"][0].tolist(), "chk": int(out["parents"].astype(np.int64).sum())},
+          open(os.path.join(os.environ["RC_OUT"], f"r{rank}.json"), "w"))
+d.barrier()
+'''
+
+
+def test_two_rank_gloo_sharding(tmp_path):
+    """world_size 2 on CPU (gloo): disjoint shards, rank-distinct RNG streams, reporting reductions only."""
+    import json
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, RC_ROOT=ROOT, RC_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", str(script)]
+    subprocess.run(cmd, check=True, env=env, timeout=240, capture_output=True)
+    r0, r1 = (json.load(open(tmp_path / f"r{i}.json")) for i in (0, 1))
+    assert (r0["lo"], r0["hi"], r1["lo"], r1["hi"]) == (0, 501, 501, 1001)
+    assert r0["total"] == r1["total"] == 1001.0 and r0["max"] == r1["max"] == 1.0
+    assert r0["first_actions"] != r1["first_actions"]           # independent streams per rank
+    from oracle.oracle_np import Oracle
+    assert r0["first_actions"] == Oracle().rng_actions(77, 0, 0, 6, 12).tolist()  # reproducible

@@ -152,10 +152,8 @@ def main():
         extras["step_dense_f32_1M"] = {"steps_per_s": m / t, "GBps": (114 + 1920) * m / t / 1e9}
         del oh
         W, D = 100_000, 30
-        p = _lib.pitch_for(W)
-        z = lambda *s: torch.empty(s, dtype=torch.uint8, device=dev)
-        ab = dict(actions_out=z(D, p), parents=z(D, 54, p), children=z(D, 12, 54, p), child_solved=z(D, 12, p))
-        t = timed(lambda: ops.adi_generate(W, D, CUBE, p, dev, seed=2024, **ab), iters=5)
+        pt, ab = ops.adi_buffers(W, D, CUBE, dev, parents=True, children=True)      # 4096-walk tiles per (depth, child)
+        t = timed(lambda: ops.adi_generate(W, D, CUBE, pt, dev, seed=2024, **ab), iters=5)
         extras["adi_100k_x30"] = {"units_per_s": W * D / t, "steps_per_s": 13 * W * D / t, "GBps": 715 * W * D / t / 1e9}
         del ab
 

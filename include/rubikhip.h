@@ -115,10 +115,13 @@ int rc_encode(const uint8_t *st, int64_t n_cubes, int64_t pitch, int cube_size, 
 int rc_onehot_from_code(const uint8_t *code, int64_t n_cubes, int64_t code_pitch, int cube_size,
                         void *onehot, int fmt, void *stream);
 
-/* All A children of every cube, into PLAIN buffers (pitch_out >= n_cubes, % 16 == 0):
- * children[(a*S + s) * pitch_out + n], child_solved[a * pitch_out + n],
- * child_code[(a*SLOTS + slot) * pitch_out + n] (NULL to skip).  `in` may be tiled.  Replaces the child loops of
- * CubeEnv.get_target_value (cube_env.py:212-236) and MCTS.expand (mcts.py:96-101). */
+/* All A children of every cube.  Outputs use one tiling (pitch_out, tiles = ceil(n / pitch_out)
+ * when n > pitch_out, else 1), child-major:
+ *   children     [A][tiles][S][pitch_out]        child a = a tiled state buffer of its own
+ *   child_code   [A][tiles][SLOTS][pitch_out]
+ *   child_solved [A][tiles * pitch_out]          flag of child a of cube n at [a][n]
+ * (any may be NULL).  With one tile this is children[(a*S + s) * pitch_out + n].  `in` may be tiled too.
+ * Replaces the child loops of CubeEnv.get_target_value (cube_env.py:212-236) and MCTS.expand (mcts.py:96-101). */
 int rc_expand_children(const uint8_t *in, int64_t n_cubes, int64_t pitch_in, int cube_size,
                        uint8_t *children, uint8_t *child_solved, uint8_t *child_code,
                        int64_t pitch_out, void *stream);
@@ -129,13 +132,15 @@ int rc_expand_children(const uint8_t *in, int64_t n_cubes, int64_t pitch_in, int
  *   actions_in   NULL: moves are drawn on the device, walk w (global index walk_offset + w)
  *                uses xoroshiro128+ seeded by splitmix64 from (seed, stream_id, walk)
  *                (DESIGN.md "RNG"); non-NULL: replay actions_in[d * pitch + w].
- *   actions_out  [depth][pitch]                 (NULL to skip)
- *   parents      [depth][S][pitch]              (NULL to skip)
- *   parent_code  [depth][SLOTS][pitch]          (NULL to skip)
- *   children     [depth][A][S][pitch]           (NULL to skip)
- *   child_code   [depth][A][SLOTS][pitch]       (NULL to skip)
- *   child_solved [depth][A][pitch]              (NULL to skip)
- * All buffers are plain: pitch >= n_walks, pitch % 16 == 0. */
+ * Layouts, with tiles = ceil(n_walks / pitch) when n_walks > pitch (then pitch is a power of two
+ * >= 1024), else 1, and Wp = tiles * pitch (any pointer may be NULL to skip that output):
+ *   actions_in / actions_out  [depth][Wp]
+ *   parents      [depth][tiles][S][pitch]          one tiled state buffer per depth
+ *   parent_code  [depth][tiles][SLOTS][pitch]
+ *   children     [depth][A][tiles][S][pitch]       one tiled state buffer per (depth, child)
+ *   child_code   [depth][A][tiles][SLOTS][pitch]
+ *   child_solved [depth][A][Wp]
+ * With one tile these are the plain [depth][A][S][pitch] arrays. */
 int rc_adi_generate(uint64_t seed, uint64_t stream_id, int64_t walk_offset, int64_t n_walks,
                     int depth, int cube_size, int64_t pitch, const uint8_t *actions_in,
                     uint8_t *actions_out, uint8_t *parents, uint8_t *parent_code,

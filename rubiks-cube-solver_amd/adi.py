@@ -49,16 +49,14 @@ def adi_samples(model, cube_size, n_walks, depth, temperature, device="cuda", mo
     acts_all = None if actions is None else torch.as_tensor(actions, dtype=torch.uint8)
     for w0 in range(0, n_walks, chunk):
         wc = min(chunk, n_walks - w0)
-        p = _lib.pitch_for(wc)
-        z = lambda *s: torch.empty(s, dtype=torch.uint8, device=dev)
-        bufs = dict(actions_out=z(depth, p), parent_code=z(depth, SL, p), child_code=z(depth, A, SL, p),
-                    child_solved=z(depth, A, p))
+        pitch, bufs = ops.adi_buffers(wc, depth, cube_size, dev, parent_code=True, child_code=True)
+        p = bufs["actions_out"].shape[1]                      # padded walk count (tiles * pitch)
         a_in = None
         if acts_all is not None:
             a_host = torch.zeros((depth, p), dtype=torch.uint8)
             a_host[:, :wc] = acts_all[w0:w0 + wc].t()
             a_in = a_host.to(dev)
-        ops.adi_generate(wc, depth, cube_size, p, dev, seed=seed, stream_id=stream_id, walk_offset=walk_offset + w0,
+        ops.adi_generate(wc, depth, cube_size, pitch, dev, seed=seed, stream_id=stream_id, walk_offset=walk_offset + w0,
                          actions_in=a_in, **bufs)
         dense = torch.empty(((A + 1) * wc, R, C), dtype=torch.float32, device=dev)
         child_value = torch.zeros((A, p), dtype=torch.float32, device=dev)
@@ -74,7 +72,7 @@ def adi_samples(model, cube_size, n_walks, depth, temperature, device="cuda", mo
             pv = v[A * wc:].contiguous()
             w = torch.full((wc,), weights[d], dtype=torch.float64, device=dev)
             tv[d], tp[d], err[d] = ops.adi_targets(child_value, bufs["child_solved"][d], wc, cube_size, pv, w)
-        outs["state_code"].append(bufs["parent_code"][:, :, :wc].permute(2, 0, 1).contiguous())
+        outs["state_code"].append(torch.stack([ops.to_aos(bufs["parent_code"][d], wc) for d in range(depth)], 1).contiguous())
         outs["actions"].append(bufs["actions_out"][:, :wc].t().contiguous())
         outs["target_value"].append(tv.t().contiguous())
         outs["target_policy"].append(tp.t().contiguous())

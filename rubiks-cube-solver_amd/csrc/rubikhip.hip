@@ -189,8 +189,8 @@ struct ExpandArgs {
     const uint8_t *in;
     int64_t n, pitch_in;
     uint8_t *children, *child_solved, *child_code;
-    int64_t pitch_out;
-    int parts, sh_in;
+    int64_t pitch_out, tiles_out;
+    int parts, sh_in, sh_out;
 };
 
 // Row addressing: every row pointer handed to these helpers is WAVE-UNIFORM (kernel argument +
@@ -203,36 +203,42 @@ __device__ __forceinline__ uint8_t *opaque(uint8_t *p) {
     return p;
 }
 
+// Where one expansion's outputs go.  Child a of the wave's cubes: a tiled state buffer of its own,
+// children + a * tiles * S * pitch (layout [A][tile][S][pitch]); codes likewise with SLOTS rows;
+// flags are [A][tiles * pitch].  The three pointers already include the wave's own offset
+// (tile_off / g0), so only the per-child strides are left.
+struct ChildOut {
+    uint8_t *children, *child_solved, *child_code;
+    int64_t pitch, tiles;
+};
+
 template <class T, int V, int A_, bool CODE>
-__device__ __forceinline__ void emit_child(const Pk<V> (&s)[T::S], const Pk<V> (&pcode)[T::SLOTS],
-                                           uint8_t *children, uint8_t *child_solved, uint8_t *child_code, int64_t pitch, uint32_t lo) {
+__device__ __forceinline__ void emit_child(const Pk<V> (&s)[T::S], const Pk<V> (&pcode)[T::SLOTS], const ChildOut &o, uint32_t lo) {
     Pk<V> c[T::S];
     fixed_move<T, V, A_>(s, c);
-    if (children) {
-        uint8_t *row = opaque(children + (int64_t)A_ * T::S * pitch);
+    if (o.children) {
+        uint8_t *row = opaque(o.children + (int64_t)A_ * T::S * o.tiles * o.pitch);
 #pragma unroll
-        for (int i = 0; i < T::S; ++i) { st<V, true>(row + lo, c[i]); row += pitch; }
+        for (int i = 0; i < T::S; ++i) { st<V, true>(row + lo, c[i]); row += o.pitch; }
     }
-    if (child_solved) st<V, true>(child_solved + (int64_t)A_ * pitch + lo, done_bytes(unsolved<T, V>(c)));
+    if (o.child_solved) st<V, true>(o.child_solved + (int64_t)A_ * o.tiles * o.pitch + lo, done_bytes(unsolved<T, V>(c)));
     if constexpr (CODE) {
         Pk<V> cc[T::SLOTS];
         encode_child<T, V, A_>(c, pcode, cc);
-        uint8_t *row = opaque(child_code + (int64_t)A_ * T::SLOTS * pitch);
+        uint8_t *row = opaque(o.child_code + (int64_t)A_ * T::SLOTS * o.tiles * o.pitch);
 #pragma unroll
-        for (int p = 0; p < T::SLOTS; ++p) { st<V, true>(row + lo, cc[p]); row += pitch; }
+        for (int p = 0; p < T::SLOTS; ++p) { st<V, true>(row + lo, cc[p]); row += o.pitch; }
     }
 }
 
 // children part, part+parts, ... of one parent pack; pointers are wave-uniform
 template <class T, int V, bool CODE>
-__device__ __forceinline__ void emit_children(const Pk<V> (&s)[T::S], int part, int parts,
-                                              uint8_t *children, uint8_t *child_solved, uint8_t *child_code, int64_t pitch, uint32_t lo) {
+__device__ __forceinline__ void emit_children(const Pk<V> (&s)[T::S], int part, int parts, const ChildOut &o, uint32_t lo) {
     Pk<V> pcode[T::SLOTS];
     if constexpr (CODE) encode<T, V>(s, pcode);
     sfor<T::A>([&](auto ac) {
         constexpr int a = decltype(ac)::value;
-        if ((a - part) % parts == 0 && a >= part)
-            emit_child<T, V, a, CODE>(s, pcode, children, child_solved, child_code, pitch, lo);
+        if ((a - part) % parts == 0 && a >= part) emit_child<T, V, a, CODE>(s, pcode, o, lo);
     });
 }
 
@@ -250,15 +256,17 @@ __global__ void __launch_bounds__(kWave) k_expand(ExpandArgs a) {
 #pragma unroll
         for (int i = 0; i < T::S; ++i) { s[i] = ld<V, false>(row + lo); row += a.pitch_in; }
     }
-    emit_children<T, V, CODE>(s, part, a.parts, a.children ? a.children + g0 : nullptr, a.child_solved ? a.child_solved + g0 : nullptr,
-                              a.child_code ? a.child_code + g0 : nullptr, a.pitch_out, lo);
+    const ChildOut o{a.children ? a.children + tile_off(g0, a.pitch_out, a.sh_out, T::S) : nullptr,
+                     a.child_solved ? a.child_solved + g0 : nullptr,
+                     a.child_code ? a.child_code + tile_off(g0, a.pitch_out, a.sh_out, T::SLOTS) : nullptr, a.pitch_out, a.tiles_out};
+    emit_children<T, V, CODE>(s, part, a.parts, o, lo);
 }
 
 // ------------------------------------------------------------------------------- ADI
 struct AdiArgs {
     uint64_t seed, stream_id;
-    int64_t walk_offset, n_walks, pitch;
-    int depth, parts;
+    int64_t walk_offset, n_walks, pitch, tiles;   // tiles * pitch = padded walk count of one [.] row
+    int depth, parts, shift;
     const uint8_t *actions_in;
     uint8_t *actions_out, *parents, *parent_code, *children, *child_code, *child_solved;
 };
@@ -286,7 +294,7 @@ __global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
     for (int d = 0; d < a.depth; ++d) {
         Pk<V> act;
         if (a.actions_in != nullptr) {
-            act = ld<V, false>(a.actions_in + (int64_t)d * a.pitch + w0);
+            act = ld<V, false>(a.actions_in + (int64_t)d * a.tiles * a.pitch + w0);
         } else {
 #pragma unroll
             for (int k = 0; k < V; ++k) {
@@ -304,9 +312,9 @@ __global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
 #pragma unroll
         for (int i = 0; i < T::S; ++i) s[i] = o[i];
         if (part == 0) {
-            if (a.actions_out) st<V, true>(a.actions_out + (int64_t)d * a.pitch + w0, act);
+            if (a.actions_out) st<V, true>(a.actions_out + (int64_t)d * a.tiles * a.pitch + w0, act);
             if (a.parents) {
-                uint8_t *row = opaque(a.parents + (int64_t)d * T::S * a.pitch + g0);
+                uint8_t *row = opaque(a.parents + (int64_t)d * T::S * a.tiles * a.pitch + tile_off(g0, a.pitch, a.shift, T::S));
 #pragma unroll
                 for (int i = 0; i < T::S; ++i) { st<V, true>(row + lo, s[i]); row += a.pitch; }
             }
@@ -314,17 +322,19 @@ __global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
                 if (a.parent_code) {
                     Pk<V> pc[T::SLOTS];
                     encode<T, V>(s, pc);
-                    uint8_t *row = opaque(a.parent_code + (int64_t)d * T::SLOTS * a.pitch + g0);
+                    uint8_t *row = opaque(a.parent_code + (int64_t)d * T::SLOTS * a.tiles * a.pitch + tile_off(g0, a.pitch, a.shift, T::SLOTS));
 #pragma unroll
                     for (int p = 0; p < T::SLOTS; ++p) { st<V, true>(row + lo, pc[p]); row += a.pitch; }
                 }
             }
         }
-        uint8_t *ch = a.children ? a.children + (int64_t)d * T::A * T::S * a.pitch + g0 : nullptr;
-        uint8_t *cs = a.child_solved ? a.child_solved + (int64_t)d * T::A * a.pitch + g0 : nullptr;
-        uint8_t *cc = a.child_code ? a.child_code + (int64_t)d * T::A * T::SLOTS * a.pitch + g0 : nullptr;
-        if (CODE && cc != nullptr) emit_children<T, V, CODE>(s, part, a.parts, ch, cs, cc, a.pitch, lo);
-        else emit_children<T, V, false>(s, part, a.parts, ch, cs, nullptr, a.pitch, lo);
+        const int64_t wp = a.tiles * a.pitch;
+        const ChildOut co{a.children ? a.children + (int64_t)d * T::A * T::S * wp + tile_off(g0, a.pitch, a.shift, T::S) : nullptr,
+                         a.child_solved ? a.child_solved + (int64_t)d * T::A * wp + g0 : nullptr,
+                         a.child_code ? a.child_code + (int64_t)d * T::A * T::SLOTS * wp + tile_off(g0, a.pitch, a.shift, T::SLOTS) : nullptr,
+                         a.pitch, a.tiles};
+        if (CODE && co.child_code != nullptr) emit_children<T, V, CODE>(s, part, a.parts, co, lo);
+        else emit_children<T, V, false>(s, part, a.parts, co, lo);
     }
 }
 
@@ -652,8 +662,8 @@ int rc_onehot_from_code(const uint8_t *code, int64_t n, int64_t code_pitch, int 
 
 int rc_expand_children(const uint8_t *in, int64_t n, int64_t pitch_in, int cube_size, uint8_t *children, uint8_t *child_solved,
                        uint8_t *child_code, int64_t pitch_out, void *stream) {
-    const int sh_in = tile_shift(pitch_in, n);
-    if (!in || !aligned16(in) || n < 0 || sh_in < 0 || bad_pitch(pitch_out, n)) return fail(RC_EINVAL, "rc_expand_children: bad buffer / pitch%s");
+    const int sh_in = tile_shift(pitch_in, n), sh_out = tile_shift(pitch_out, n);
+    if (!in || !aligned16(in) || n < 0 || sh_in < 0 || sh_out < 0) return fail(RC_EINVAL, "rc_expand_children: bad buffer / pitch%s");
     if (!children && !child_solved && !child_code) return fail(RC_EINVAL, "rc_expand_children: nothing to write%s");
     if ((children && !aligned16(children)) || (child_solved && !aligned16(child_solved)) || (child_code && !aligned16(child_code)))
         return fail(RC_EINVAL, "rc_expand_children: outputs must be 16-byte aligned%s");
@@ -662,7 +672,8 @@ int rc_expand_children(const uint8_t *in, int64_t n, int64_t pitch_in, int cube_
         using T = decltype(t);
         const int V = n >= ((int64_t)1 << 20) ? 2 : 1;
         const int64_t groups = (n + kWave * 4 * V - 1) / (kWave * 4 * V);
-        ExpandArgs a{in, n, pitch_in, children, child_solved, child_code, pitch_out, parts_for(groups, T::A), sh_in};
+        ExpandArgs a{in, n, pitch_in, children, child_solved, child_code, pitch_out, n <= pitch_out ? 1 : (n + pitch_out - 1) / pitch_out,
+                     parts_for(groups, T::A), sh_in, sh_out};
         const dim3 g((unsigned)(groups * a.parts)), b(kWave);
         hipStream_t st = S(stream);
         if (V == 2) {
@@ -680,7 +691,8 @@ int rc_expand_children(const uint8_t *in, int64_t n, int64_t pitch_in, int cube_
 int rc_adi_generate(uint64_t seed, uint64_t stream_id, int64_t walk_offset, int64_t n_walks, int depth, int cube_size, int64_t pitch,
                     const uint8_t *actions_in, uint8_t *actions_out, uint8_t *parents, uint8_t *parent_code, uint8_t *children,
                     uint8_t *child_code, uint8_t *child_solved, void *stream) {
-    if (n_walks < 0 || depth < 0 || bad_pitch(pitch, n_walks)) return fail(RC_EINVAL, "rc_adi_generate: bad sizes / pitch%s");
+    const int sh = tile_shift(pitch, n_walks);
+    if (n_walks < 0 || depth < 0 || sh < 0) return fail(RC_EINVAL, "rc_adi_generate: bad sizes / pitch%s");
     const void *ptrs[] = {actions_in, actions_out, parents, parent_code, children, child_code, child_solved};
     for (const void *p : ptrs)
         if (p && !aligned16(p)) return fail(RC_EINVAL, "rc_adi_generate: buffers must be 16-byte aligned%s");
@@ -690,8 +702,8 @@ int rc_adi_generate(uint64_t seed, uint64_t stream_id, int64_t walk_offset, int6
         const int V = 1;
         const int64_t groups = (n_walks + kWave * 4 * V - 1) / (kWave * 4 * V);
         const bool any_child = children || child_code || child_solved;
-        AdiArgs a{seed, stream_id, walk_offset, n_walks, pitch, depth, any_child ? parts_for(groups, T::A) : 1,
-                  actions_in, actions_out, parents, parent_code, children, child_code, child_solved};
+        AdiArgs a{seed, stream_id, walk_offset, n_walks, pitch, n_walks <= pitch ? 1 : (n_walks + pitch - 1) / pitch, depth,
+                  any_child ? parts_for(groups, T::A) : 1, sh, actions_in, actions_out, parents, parent_code, children, child_code, child_solved};
         const dim3 g((unsigned)(groups * a.parts)), b(kWave);
         if (parent_code || child_code) hipLaunchKernelGGL((k_adi<T, 1, true>), g, b, 0, S(stream), a);
         else hipLaunchKernelGGL((k_adi<T, 1, false>), g, b, 0, S(stream), a);

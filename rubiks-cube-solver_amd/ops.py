@@ -177,40 +177,109 @@ def onehot_from_code(code, n, cube_size, onehot):
     check(lib().rc_onehot_from_code(ptr(code), n, cp, cube_size, ptr(onehot), fmt, stream_ptr(code.device)))
 
 
-def expand_children(st, n, cube_size, children=None, child_solved=None, child_code=None):
-    """children [A,S,pitch], child_solved [A,pitch], child_code [A,SLOTS,pitch] (same pitch)."""
+def _tiles_of(n, pitch):
+    if pitch % 16:
+        raise RubikHipError(f"pitch {pitch} must be a multiple of 16")
+    if n <= pitch:
+        return 1
+    if pitch < 1024 or pitch & (pitch - 1):
+        raise RubikHipError(f"{n} cubes in tiles of {pitch}: several tiles need a power-of-two pitch >= 1024")
+    return -(-n // pitch)
+
+
+def _out(t, lead, tiles, rows, pitch, what):
+    """Output buffer [*lead, tiles, rows, pitch] (the tile axis may be dropped when tiles == 1; rows == 0 means
+    a flag / action array [*lead, tiles * pitch])."""
+    if t is None:
+        return
+    if t.dtype != torch.uint8 or not t.is_cuda or not t.is_contiguous():
+        raise RubikHipError(f"{what}: need a contiguous uint8 HIP tensor")
+    want = (*lead, tiles * pitch) if rows == 0 else (*lead, tiles, rows, pitch)
+    ok = tuple(t.shape) == want or (rows and tiles == 1 and tuple(t.shape) == (*lead, rows, pitch))
+    if not ok:
+        raise RubikHipError(f"{what}: shape {tuple(t.shape)}, expected {want}")
+
+
+def expand_buffers(n, cube_size, device, pitch=None, children=False, codes=True):
+    """Allocate rc_expand_children outputs: child_solved [A, Wp], child_code [A, tiles, SLOTS, pitch],
+    children [A, tiles, S, pitch]."""
+    S, A, SL = _size(cube_size)
+    tiles, pitch = _tile_shape(n, pitch)
+    e = lambda *s: torch.empty(s, dtype=torch.uint8, device=device)
+    out = {"child_solved": e(A, tiles * pitch)}
+    if codes:
+        out["child_code"] = e(A, tiles, SL, pitch)
+    if children:
+        out["children"] = e(A, tiles, S, pitch)
+    return out
+
+
+def expand_children(st, n, cube_size, children=None, child_solved=None, child_code=None, pitch=None):
+    """All A children of every cube (cube_env.py:212-236, mcts.py:96-101).  Outputs share one tiling:
+    children [A, tiles, S, pitch], child_code [A, tiles, SLOTS, pitch], child_solved [A, tiles * pitch]
+    (tile axis optional when tiles == 1).  `pitch` defaults to the last dim of the first output given."""
     S, A, SL = _size(cube_size)
     p_in = _tiled(st, S, n, "expand src")
-    pitches = set()
-    if children is not None:
-        pitches.add(_rows(children, S, n, "children"))
-        if children.shape[0] != A:
-            raise RubikHipError("children: first dim must be A")
-    if child_solved is not None:
-        pitches.add(_rows(child_solved, A, n, "child_solved"))
-    if child_code is not None:
-        pitches.add(_rows(child_code, SL, n, "child_code"))
-        if child_code.shape[0] != A:
-            raise RubikHipError("child_code: first dim must be A")
-    if len(pitches) != 1:
-        raise RubikHipError("expand_children: outputs must share one pitch")
+    if pitch is None:
+        ref = children if children is not None else child_code
+        if ref is not None:
+            pitch = ref.shape[-1]
+        elif child_solved is not None:
+            pitch = child_solved.shape[-1] if n <= child_solved.shape[-1] and child_solved.shape[-1] % 16 == 0 else None
+        if pitch is None:
+            raise RubikHipError("expand_children: cannot infer the output pitch, pass pitch=")
+        if child_solved is not None and children is None and child_code is None and n > pitch:
+            raise RubikHipError("expand_children: pass pitch= for a tiled flag buffer")
+    tiles = _tiles_of(n, pitch)
+    _out(children, (A,), tiles, S, pitch, "children")
+    _out(child_code, (A,), tiles, SL, pitch, "child_code")
+    _out(child_solved, (A,), tiles, 0, pitch, "child_solved")
+    if children is None and child_solved is None and child_code is None:
+        raise RubikHipError("expand_children: nothing to write")
     _lib.init(st.device)
     check(lib().rc_expand_children(ptr(st), n, p_in, cube_size, ptr(children), ptr(child_solved), ptr(child_code),
-                                   pitches.pop(), stream_ptr(st.device)))
+                                   pitch, stream_ptr(st.device)))
+
+
+ADI_TILE = 4096
+
+
+def adi_buffers(n_walks, depth, cube_size, device, pitch=None, actions=True, parents=False, parent_code=False,
+                children=False, child_code=False, child_solved=True):
+    """Allocate rc_adi_generate outputs with one tiling (see include/rubikhip.h).  Returns (pitch, dict)."""
+    S, A, SL = _size(cube_size)
+    if pitch is None:
+        pitch = _lib.pitch_for(n_walks) if n_walks <= ADI_TILE else ADI_TILE
+    tiles = _tiles_of(n_walks, pitch)
+    e = lambda *s: torch.empty(s, dtype=torch.uint8, device=device)
+    out = {}
+    if actions:
+        out["actions_out"] = e(depth, tiles * pitch)
+    if parents:
+        out["parents"] = e(depth, tiles, S, pitch)
+    if parent_code:
+        out["parent_code"] = e(depth, tiles, SL, pitch)
+    if children:
+        out["children"] = e(depth, A, tiles, S, pitch)
+    if child_code:
+        out["child_code"] = e(depth, A, tiles, SL, pitch)
+    if child_solved:
+        out["child_solved"] = e(depth, A, tiles * pitch)
+    return pitch, out
 
 
 def adi_generate(n_walks, depth, cube_size, pitch, device, seed=0, stream_id=0, walk_offset=0, actions_in=None,
                  actions_out=None, parents=None, parent_code=None, children=None, child_code=None, child_solved=None):
-    """ADI walks + expansion (cube_env.py:177-194,212-236); see include/rubikhip.h for layouts."""
+    """ADI walks + expansion (cube_env.py:177-194,212-236); layouts in include/rubikhip.h / adi_buffers."""
     S, A, SL = _size(cube_size)
-    shapes = dict(actions_in=(depth, pitch), actions_out=(depth, pitch), parents=(depth, S, pitch),
-                  parent_code=(depth, SL, pitch), children=(depth, A, S, pitch), child_code=(depth, A, SL, pitch),
-                  child_solved=(depth, A, pitch))
-    bufs = dict(actions_in=actions_in, actions_out=actions_out, parents=parents, parent_code=parent_code,
-                children=children, child_code=child_code, child_solved=child_solved)
-    for k, t in bufs.items():
-        if t is not None and (tuple(t.shape) != shapes[k] or t.dtype != torch.uint8 or not t.is_cuda or not t.is_contiguous()):
-            raise RubikHipError(f"adi_generate: {k} must be a contiguous uint8 HIP tensor of shape {shapes[k]}")
+    tiles = _tiles_of(n_walks, pitch)
+    _out(actions_in, (depth,), tiles, 0, pitch, "actions_in")
+    _out(actions_out, (depth,), tiles, 0, pitch, "actions_out")
+    _out(parents, (depth,), tiles, S, pitch, "parents")
+    _out(parent_code, (depth,), tiles, SL, pitch, "parent_code")
+    _out(children, (depth, A), tiles, S, pitch, "children")
+    _out(child_code, (depth, A), tiles, SL, pitch, "child_code")
+    _out(child_solved, (depth, A), tiles, 0, pitch, "child_solved")
     dev = torch.device(device)
     _lib.init(dev)
     check(lib().rc_adi_generate(seed, stream_id, walk_offset, n_walks, depth, cube_size, pitch, ptr(actions_in),

@@ -139,18 +139,14 @@ class VecCubeEnv:
         t = torch.as_tensor(states, dtype=torch.uint8).cpu()
         self.stickers.copy_(ops.from_aos(t, self.device, self.stickers.shape[2]))
 
-    def expand(self, children=False, codes=True):
+    def expand(self, children=False, codes=True, pitch=None):
         """All A children of every cube (cube_env.py:212-236, mcts.py:96-101).
-        Returns dict(child_solved [A, pitch], child_code [A, SLOTS, pitch], children [A, S, pitch])."""
+        Returns dict(child_solved [A, Wp], child_code [A, tiles, SLOTS, pitch], children [A, tiles, S, pitch]);
+        ops.to_aos(buf[a], n) turns one child's tiled buffer into [n, rows]."""
         n, cs = self.num_envs, self.cube_size
-        p = _lib.pitch_for(n)
-        S, A, SL = ops.N_STICKERS[cs], self.action_dim, ops.N_SLOTS[cs]
-        out = {"child_solved": torch.empty((A, p), dtype=torch.uint8, device=self.device)}
-        if codes:
-            out["child_code"] = torch.empty((A, SL, p), dtype=torch.uint8, device=self.device)
-        if children:
-            out["children"] = torch.empty((A, S, p), dtype=torch.uint8, device=self.device)
-        ops.expand_children(self.stickers, n, cs, out.get("children"), out["child_solved"], out.get("child_code"))
+        _, pitch = ops._tile_shape(n, pitch)
+        out = ops.expand_buffers(n, cs, self.device, pitch, children=children, codes=codes)
+        ops.expand_children(self.stickers, n, cs, out.get("children"), out["child_solved"], out.get("child_code"), pitch=pitch)
         return out
 
     def check_actions(self):

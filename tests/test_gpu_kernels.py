@@ -43,6 +43,16 @@ def to_host(t, n):
     return np.ascontiguousarray(t[..., :n].cpu().numpy().swapaxes(-1, -2))
 
 
+def untile(t, n, lead):
+    """[*lead, tiles, rows, pitch] (or [*lead, rows, pitch]) -> numpy [*lead, n, rows]."""
+    from rubiks_cube_solver_amd import ops
+    if t.dim() == lead + 2:
+        t = t.unsqueeze(lead)
+    flat = t.reshape(-1, *t.shape[lead:])
+    out = torch.stack([ops.to_aos(x, n) for x in flat]).reshape(*t.shape[:lead], n, t.shape[-2])
+    return out.cpu().numpy()
+
+
 def code_buf(ops, n, cs, like):
     """zeroed code buffer with the same tiling as the state buffer `like`."""
     return torch.zeros((like.shape[0], SL_OF[cs], like.shape[2]), dtype=torch.uint8, device="cuda")
@@ -204,9 +214,11 @@ def test_golden_encode_arbitrary_colourings(ops, L, golden):
 
 
 @pytest.mark.parametrize("cs", CS)
-@pytest.mark.parametrize("n", [1, 37, 512, 4096, 70000])
-def test_expand_children(ops, L, oracle, cs, n):
+@pytest.mark.parametrize("n,pitch", [(1, None), (37, None), (512, None), (4096, None), (4096, 1024), (70000, None), (70000, 2048)])
+def test_expand_children(ops, L, oracle, cs, n, pitch):
     S, A, SL = S_OF[cs], A_OF[cs], SL_OF[cs]
+    if pitch is not None:
+        return _expand_tiled(ops, oracle, cs, n, pitch)
     states = random_states(oracle, cs, n, 20, seed=n)
     states[: max(1, n // 7)] = oracle.step(cs, oracle.solved(cs, max(1, n // 7)), np.arange(max(1, n // 7)) % A)[0]
     ch, cc, cso = oracle.expand(cs, states, threads=4)
@@ -224,6 +236,20 @@ def test_expand_children(ops, L, oracle, cs, n):
     assert torch.equal(solved[:, :n], solved2[:, :n])
 
 
+def _expand_tiled(ops, oracle, cs, n, pitch):
+    A = A_OF[cs]
+    states = random_states(oracle, cs, n, 20, seed=n)
+    ch, cc, cso = oracle.expand(cs, states, threads=4)
+    out = ops.expand_buffers(n, cs, "cuda", pitch, children=True, codes=True)
+    for v in out.values():
+        v.fill_(9)
+    ops.expand_children(to_dev(states), n, cs, out["children"], out["child_solved"], out["child_code"], pitch=pitch)
+    assert out["children"].shape[1] > 1
+    assert (untile(out["children"], n, 1).transpose(1, 0, 2) == ch).all()
+    assert (untile(out["child_code"], n, 1).transpose(1, 0, 2) == cc).all()
+    assert (out["child_solved"][:, :n].cpu().numpy().T == cso).all()
+
+
 def test_golden_expand(ops, L, golden):
     g = golden("expand_333")
     n = len(g["leaves"])
@@ -239,34 +265,36 @@ def test_golden_expand(ops, L, golden):
 
 
 @pytest.mark.parametrize("cs", CS)
-@pytest.mark.parametrize("n_walks,depth", [(1, 1), (5, 3), (300, 30), (5000, 7)])
+@pytest.mark.parametrize("n_walks,depth,pitch", [(1, 1, None), (5, 3, None), (300, 30, None), (5000, 7, None), (5000, 7, 1024),
+                                                 (3000, 4, 2048)])
 @pytest.mark.parametrize("replay", [False, True])
-def test_adi_generate(ops, L, oracle, cs, n_walks, depth, replay):
+def test_adi_generate(ops, L, oracle, cs, n_walks, depth, pitch, replay):
     S, A, SL = S_OF[cs], A_OF[cs], SL_OF[cs]
-    p = L.pitch_for(n_walks)
-    z = lambda *shape: torch.zeros(shape, dtype=torch.uint8, device="cuda")
-    bufs = dict(actions_out=z(depth, p), parents=z(depth, S, p), parent_code=z(depth, SL, p),
-                children=z(depth, A, S, p), child_code=z(depth, A, SL, p), child_solved=z(depth, A, p))
+    pitch, bufs = ops.adi_buffers(n_walks, depth, cs, "cuda", pitch or L.pitch_for(n_walks), parents=True, parent_code=True,
+                                  children=True, child_code=True)
+    for v in bufs.values():
+        v.fill_(7)
+    wp = bufs["actions_out"].shape[1]
     kw = {}
     exp_kw = dict(seed=2024, stream=3, walk0=11)
     if replay:
         acts = np.random.default_rng(5).integers(0, A, (n_walks, depth), dtype=np.uint8)
-        a_in = z(depth, p)
+        a_in = torch.zeros((depth, wp), dtype=torch.uint8, device="cuda")
         a_in[:, :n_walks] = torch.from_numpy(np.ascontiguousarray(acts.T)).cuda()
         kw["actions_in"] = a_in
         exp_kw["actions_in"] = acts
     exp = oracle.adi(cs, n_walks, depth, threads=4, **exp_kw)
-    ops.adi_generate(n_walks, depth, cs, p, "cuda", seed=2024, stream_id=3, walk_offset=11, **kw, **bufs)
+    ops.adi_generate(n_walks, depth, cs, pitch, "cuda", seed=2024, stream_id=3, walk_offset=11, **kw, **bufs)
     assert L.read_status() == 0
     assert (bufs["actions_out"][:, :n_walks].cpu().numpy().T == exp["actions"]).all()
-    assert (to_host(bufs["parents"], n_walks).transpose(1, 0, 2) == exp["parents"]).all()
-    assert (to_host(bufs["parent_code"], n_walks).transpose(1, 0, 2) == exp["parent_code"]).all()
-    assert (to_host(bufs["children"], n_walks).transpose(2, 0, 1, 3) == exp["children"]).all()
-    assert (to_host(bufs["child_code"], n_walks).transpose(2, 0, 1, 3) == exp["child_code"]).all()
+    assert (untile(bufs["parents"], n_walks, 1).transpose(1, 0, 2) == exp["parents"]).all()
+    assert (untile(bufs["parent_code"], n_walks, 1).transpose(1, 0, 2) == exp["parent_code"]).all()
+    assert (untile(bufs["children"], n_walks, 2).transpose(2, 0, 1, 3) == exp["children"]).all()
+    assert (untile(bufs["child_code"], n_walks, 2).transpose(2, 0, 1, 3) == exp["child_code"]).all()
     assert (bufs["child_solved"][..., :n_walks].cpu().numpy().transpose(2, 0, 1) == exp["child_solved"]).all()
     # subsets of outputs give the same bytes
-    cs2 = z(depth, A, p)
-    ops.adi_generate(n_walks, depth, cs, p, "cuda", seed=2024, stream_id=3, walk_offset=11, child_solved=cs2, **kw)
+    cs2 = torch.zeros_like(bufs["child_solved"])
+    ops.adi_generate(n_walks, depth, cs, pitch, "cuda", seed=2024, stream_id=3, walk_offset=11, child_solved=cs2, **kw)
     assert torch.equal(cs2[..., :n_walks], bufs["child_solved"][..., :n_walks])
 
 

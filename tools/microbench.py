@@ -78,28 +78,30 @@ def main():
             del oh
     if "adi" in which:
         W, D = 100_000, 30
-        p = _lib.pitch_for(W)
-        z = lambda *s: torch.empty(s, dtype=torch.uint8, device="cuda")
-        bufs = dict(actions_out=z(D, p), parents=z(D, 54, p), children=z(D, 12, 54, p), child_solved=z(D, 12, p))
-        t = timeit(lambda: ops.adi_generate(W, D, 3, p, "cuda", seed=2024, **bufs), iters=5, warm=2)
-        out.append(dict(k="adi_100k_x30_stickers", ms=t * 1e3, Gunits=W * D / t / 1e9, GBps=715 * W * D / t / 1e9))
-        del bufs["children"]
-        bufs["child_code"] = z(D, 12, 20, p)
-        bufs["parent_code"] = z(D, 20, p)
-        t = timeit(lambda: ops.adi_generate(W, D, 3, p, "cuda", seed=2024, **bufs), iters=5, warm=2)
-        out.append(dict(k="adi_100k_x30_codes", ms=t * 1e3, Gunits=W * D / t / 1e9,
-                        GBps=(54 + 1 + 12 + 13 * 20) * W * D / t / 1e9))
-        del bufs
+        for pitch in (None, 1024, 2048, 4096, 16384, 65536):
+            tag = "plain" if pitch is None else f"tile{pitch}"
+            pt, bufs = ops.adi_buffers(W, D, 3, "cuda", pitch or _lib.pitch_for(W), parents=True, children=True)
+            t = timeit(lambda: ops.adi_generate(W, D, 3, pt, "cuda", seed=2024, **bufs), iters=5, warm=2)
+            out.append(dict(k=f"adi_100k_x30_stickers_{tag}", ms=t * 1e3, Gunits=W * D / t / 1e9, GBps=715 * W * D / t / 1e9))
+            del bufs
+            pt, bufs = ops.adi_buffers(W, D, 3, "cuda", pitch or _lib.pitch_for(W), parents=True, parent_code=True, child_code=True)
+            t = timeit(lambda: ops.adi_generate(W, D, 3, pt, "cuda", seed=2024, **bufs), iters=5, warm=2)
+            out.append(dict(k=f"adi_100k_x30_codes_{tag}", ms=t * 1e3, Gunits=W * D / t / 1e9,
+                            GBps=(54 + 1 + 12 + 13 * 20) * W * D / t / 1e9))
+            del bufs
     if "expand" in which:
         for m in (4096, 1 << 20):
-            p = _lib.pitch_for(m)
             src = ops.alloc_states(m, 3, "cuda")
             ops.fill_solved(src, m, 3)
             ops.scramble(src, m, 3, 20, seed=5)
-            ch = torch.empty((12, 54, p), dtype=torch.uint8, device="cuda")
-            cs = torch.empty((12, p), dtype=torch.uint8, device="cuda")
-            t = timeit(lambda: ops.expand_children(src, m, 3, ch, cs), iters=20)
-            out.append(dict(k=f"expand_{m}", us=t * 1e6, GBps=(54 + 13 * 54 + 12) * m / t / 1e9))
+            for pitch in (None, 1024, 16384):
+                if pitch is not None and m <= pitch:
+                    continue
+                o = ops.expand_buffers(m, 3, "cuda", pitch or _lib.pitch_for(m), children=True, codes=False)
+                pt = o["children"].shape[-1]
+                t = timeit(lambda: ops.expand_children(src, m, 3, o["children"], o["child_solved"], pitch=pt), iters=20)
+                out.append(dict(k=f"expand_{m}_{'plain' if pitch is None else pitch}", us=t * 1e6, GBps=(54 + 12 * 54 + 12) * m / t / 1e9))
+                del o
     for r in out:
         print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}))
 

@@ -24,7 +24,10 @@
  *     re-entrant, and keep no mutable state besides the per-device status word.
  *   - Return value: RC_OK or a negative RC_E* code; rc_last_error() gives the message of
  *     the calling thread's last failure.  Nothing is thrown across the ABI.
- *   - Out-of-range actions are the reference's IndexError (cube_env.py:86,96).  On the
+ *   - The action value A itself (12 | 6) is a NO-OP: the cube is left unchanged (its done /
+ *     reward / one-hot are still written).  Batched rollouts use it to park finished cubes and to
+ *     pad scrambles of different lengths.  The reference has no such action.
+ *   - Out-of-range actions (> A) are the reference's IndexError (cube_env.py:86,96).  On the
  *     device they cannot raise: the cube is left in an unspecified (in-bounds) state and
  *     bit RC_STATUS_BAD_ACTION of the status word is set; rc_read_status() reports it.
  *

@@ -132,7 +132,8 @@ __device__ __forceinline__ void st_tail(uint8_t *base, int64_t n0, int64_t n, Pk
 // m[a] selects (per byte) the cubes whose action is a.  Only the bits a sticker can use
 // (0..2) are guaranteed: mask bytes are 0x07 (a < 8) or 0xff (a >= 8); a stray 0x80 can show
 // for a >= 8 on cubes with an odd action < 8 -- stickers never carry bit 7, so it selects 0 from 0.
-// Returns, per byte, non-zero where the action is not in 0..A-1.
+// The action value A (12 | 6) is the NO-OP: every mask reads 0x00 for it, the cube stays put.
+// Returns, per byte, non-zero where the action is neither 0..A-1 nor the no-op.
 constexpr uint64_t mask_data(int a) {
     // a < 8: selector a reads byte a = 0x07; a >= 8: selector a reads the sign of byte 2*(a-8)+1 = 0x80
     return a < 8 ? (0x07ull << (8 * (a & 7))) : (0x80ull << (8 * (2 * ((a - 8) & 3) + 1)));
@@ -148,7 +149,11 @@ __device__ __forceinline__ Pk<V> action_masks(Pk<V> act, Pk<V> (&m)[T::A]) {
     });
     Pk<V> big = perm<V>(0u, 0u, act);  // 0xff where the byte is >= 13: every mask above read 0xff
     Pk<V> bad;
-    RC_V bad.d[k] = (~seen.d[k] & 0x07070707u) | big.d[k];
+    RC_V {
+        const uint32_t x = act.d[k] ^ ((uint32_t)T::A * 0x01010101u);                       // 0 where action == A
+        const uint32_t not_noop = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) >> 7 & 0x01010101u;  // 1 where action != A
+        bad.d[k] = ((~seen.d[k] & 0x07070707u) | big.d[k]) & (not_noop * 0xffu);
+    }
     return bad;
 }
 

@@ -1,0 +1,207 @@
+"""MCTS on the batched env (config 5 of BASELINE.json).
+
+The reference's tree search (mcts.py:12-147) spends its env time in `expand` (mcts.py:83-113):
+13 `copy.deepcopy(env)` and 12 `env.step` per leaf, with children keyed by
+`np.array2string(one-hot)`.  Here a leaf's 12 children, their solved flags and their compact
+one-hot codes come from ONE rc_expand_children launch, and a node's key is its 20-byte (7-byte)
+code -- lossless, 24x smaller than the printed one-hot.
+
+  MCTS         same class surface as the reference (train / traverse / expand / backpropagate /
+               get_most_promising_action_index) over one CubeEnv; statistics follow mcts.py.
+  BatchedMCTS  R independent roots searched in lockstep: per simulation ONE replay launch brings all
+               R leaves into a device buffer (paths padded with the no-op), ONE expansion launch
+               produces R x A children on a side stream while the value/policy net runs on the R
+               leaves; tree statistics stay on the host.
+
+Tree rules restated from mcts.py: PUCT score U + W - L with U = c * P * sqrt(sum N) / (1 + N)
+(:148-169); W is the MAX of backed-up values (:124-125); a traversed edge gains the virtual loss and
+loses it again on back-propagation (:77,127); an untried node picks a uniformly random action while
+its visit counts are all zero (:69-70).
+"""
+from __future__ import annotations
+
+import copy
+import math
+import random
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .tables import get_env_config
+
+
+class _Node:
+    __slots__ = ("children", "policy", "value", "visits", "vloss", "done")
+
+    def __init__(self, children, policy, value_min, done):
+        a = len(children)
+        self.children, self.policy, self.done = children, policy, done
+        self.value = [value_min] * a
+        self.visits = [0] * a
+        self.vloss = [0] * a
+
+
+def _puct_best(node, c):
+    total = sum(node.visits)
+    best, arg = -math.inf, 0
+    for i in range(len(node.children)):
+        s = c * float(node.policy[i]) * (math.sqrt(total) / (1 + node.visits[i])) + node.value[i] - node.vloss[i]
+        if s > best:
+            best, arg = s, i
+    return arg
+
+
+class MCTS:
+    """Drop-in for the reference's `MCTS(model, cfg)`; `train(state, env)` runs one simulation and
+    returns the action list to a solved child if one was found, else None (mcts.py:36-50)."""
+
+    def __init__(self, model, cfg):
+        self.model = model
+        self.children_and_data = dict()  # key (bytes of the compact code) -> _Node
+        self.loss_constant = cfg["mcts"]["virtual_loss_const"]
+        self.exploration_constant = cfg["mcts"]["cpuct"]
+        self.value_min = cfg["mcts"]["value_min"]
+        self.cube_size = cfg["test"]["cube_size"]
+        _, self.action_dim = get_env_config(self.cube_size)
+
+    @staticmethod
+    def key_of(env):
+        """Node key of the env's current state: its compact one-hot code."""
+        v = env._vec
+        code = ops.alloc_code(1, v.cube_size, v.device)
+        ops.encode(v.stickers, 1, v.cube_size, code, _lib.FMT_CODE)
+        return ops.to_aos(code, 1)[0].cpu().numpy().tobytes()
+
+    def train(self, state, env):
+        sim = copy.deepcopy(env)  # mcts.py:37 (one clone per simulation instead of 14)
+        path, actions, leaf_key = self.traverse(state, sim)
+        value = self.expand(leaf_key, sim)
+        self.backpropagate(path, actions, value)
+        node = self.children_and_data[leaf_key]
+        for i, d in enumerate(node.done):
+            if d:
+                actions.append(i)
+                return actions
+        return None
+
+    def traverse(self, state, env):
+        path, actions = [], []
+        current = self.key_of(env)
+        while True:
+            node = self.children_and_data.get(current)
+            if node is None or not node.children:
+                return path, actions, current
+            a = random.randint(0, self.action_dim - 1) if sum(node.visits) == 0 else _puct_best(node, self.exploration_constant)
+            path.append(current)
+            actions.append(a)
+            node.vloss[a] += self.loss_constant
+            env.step(a)
+            current = node.children[a]
+
+    def expand(self, leaf_key, env):
+        """mcts.py:83-113 with one expansion launch instead of 12 steps + 13 deep copies."""
+        value, policy = self.model.predict(env.cube)
+        ex = env._vec.expand(codes=True)
+        codes = np.stack([ops.to_aos(ex["child_code"][a], 1)[0].cpu().numpy() for a in range(self.action_dim)])
+        solved = ex["child_solved"][:, 0].cpu().numpy().astype(bool)
+        self.children_and_data[leaf_key] = _Node([c.tobytes() for c in codes], policy, self.value_min, list(solved))
+        return value
+
+    def backpropagate(self, path, actions, reward):
+        r = float(np.asarray(reward).reshape(-1)[0])
+        for key, a in zip(reversed(path), reversed(actions)):
+            node = self.children_and_data[key]
+            node.value[a] = max(node.value[a], r)
+            node.vloss[a] -= self.loss_constant  # mcts.py:127 hard-codes 150 = the config's virtual_loss_const
+            node.visits[a] += 1
+
+    def get_most_promising_action_index(self, key):
+        return _puct_best(self.children_and_data[key], self.exploration_constant)
+
+
+class BatchedMCTS:
+    """R roots searched in lockstep on one GPU (config 5: 4096 roots x 12 children per step)."""
+
+    def __init__(self, model, root_stickers, n_roots, cube_size=3, cpuct=1.0, virtual_loss=150.0, value_min=-10.0,
+                 device="cuda", overlap=True):
+        self.model, self.cube_size, self.n = model, cube_size, int(n_roots)
+        self.c, self.vl, self.vmin = cpuct, virtual_loss, value_min
+        self.dev = torch.device(device)
+        (self.R, self.C), self.A = get_env_config(cube_size)
+        self.roots = root_stickers                      # tiled state buffer [tiles, S, pitch]
+        self.work = torch.empty_like(root_stickers)
+        self.trees = [dict() for _ in range(self.n)]
+        self.solution = [None] * self.n
+        self.onehot = torch.empty((self.n, self.R, self.C), dtype=torch.float32, device=self.dev)
+        self.code = ops.alloc_code(self.n, cube_size, self.dev, root_stickers.shape[-1])
+        self.ex = ops.expand_buffers(self.n, cube_size, self.dev, root_stickers.shape[-1], children=False, codes=True)
+        self.side = torch.cuda.Stream(self.dev) if overlap else None
+
+    @torch.no_grad()
+    def leaves_step(self, paths):
+        """Device part of one simulation: replay `paths` (uint8 [R, depth], no-op padded) from the roots, then
+        expansion (side stream) || leaf one-hot + net forward (main stream).  Returns host arrays."""
+        n, cs = self.n, self.cube_size
+        self.work.copy_(self.roots)
+        if paths.shape[1]:
+            buf = torch.full((paths.shape[1], _lib.pitch_for(n)), self.A, dtype=torch.uint8)
+            buf[:, :n] = torch.from_numpy(np.ascontiguousarray(paths.T))
+            ops.scramble(self.work, n, cs, paths.shape[1], actions_in=buf.to(self.dev))
+        pitch = self.work.shape[-1]
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(self.side):
+                ops.expand_children(self.work, n, cs, None, self.ex["child_solved"], self.ex["child_code"], pitch=pitch)
+        else:
+            ops.expand_children(self.work, n, cs, None, self.ex["child_solved"], self.ex["child_code"], pitch=pitch)
+        ops.encode(self.work, n, cs, self.code, _lib.FMT_CODE)
+        ops.onehot_from_code(self.code, n, cs, self.onehot)
+        value, logits = self.model(self.onehot)
+        policy = torch.softmax(logits, dim=-1)          # model.py:89
+        if self.side is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(self.side)
+        leaf_code = ops.to_aos(self.code, n).cpu().numpy()
+        child_code = torch.stack([ops.to_aos(self.ex["child_code"][a], n) for a in range(self.A)], 1).cpu().numpy()
+        solved = self.ex["child_solved"][:, :n].t().cpu().numpy().astype(bool)
+        return leaf_code, child_code, solved, value.reshape(-1).cpu().numpy(), policy.cpu().numpy()
+
+    def simulate(self):
+        """One simulation for every unsolved root.  Returns the number of roots solved so far."""
+        n = self.n
+        paths, trails = [], []
+        for r in range(n):
+            tree, key, acts, trail = self.trees[r], b"root", [], []
+            if self.solution[r] is None:
+                while True:
+                    node = tree.get(key)
+                    if node is None or not node.children:
+                        break
+                    a = random.randint(0, self.A - 1) if sum(node.visits) == 0 else _puct_best(node, self.c)
+                    node.vloss[a] += self.vl
+                    trail.append((node, a))
+                    acts.append(a)
+                    key = node.children[a]
+            paths.append(acts)
+            trails.append((key, trail))
+        depth = max((len(p) for p in paths), default=0)
+        pad = np.full((n, depth), self.A, np.uint8)
+        for r, p in enumerate(paths):
+            pad[r, :len(p)] = p
+        leaf_code, child_code, solved, value, policy = self.leaves_step(pad)
+        for r in range(n):
+            if self.solution[r] is not None:
+                continue
+            key, trail = trails[r]
+            tree = self.trees[r]
+            kids = [child_code[r, a].tobytes() for a in range(self.A)]
+            tree[key] = _Node(kids, policy[r], self.vmin, list(solved[r]))
+            if key == b"root":
+                tree[leaf_code[r].tobytes()] = tree[key]
+            for node, a in reversed(trail):
+                node.value[a] = max(node.value[a], float(value[r]))
+                node.vloss[a] -= self.vl
+                node.visits[a] += 1
+            if solved[r].any():
+                self.solution[r] = paths[r] + [int(np.argmax(solved[r]))]
+        return sum(s is not None for s in self.solution)

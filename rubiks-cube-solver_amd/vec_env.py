@@ -78,40 +78,57 @@ class VecCubeEnv:
         """Solved, then `scramble_count` random face turns per cube (cube_env.py:50-69).
 
         seeds   : one int per env -> each env i gets exactly the reference's reset(seed=seeds[i],
-                  scramble_count) move sequence (host legacy numpy RNG, state saved/restored);
-        actions : explicit uint8 [N, scramble_count] moves (overrides seeds);
+                  scramble_count[i]) move sequence (host legacy numpy RNG, state saved/restored);
+        actions : explicit uint8 [N, K] moves (overrides seeds); the value `action_dim` is a no-op,
+                  so rows may be padded to a common length;
         neither : moves drawn on the device from (seed, stream_id, reset counter) -- reproducible,
                   rank-independent streams, no host work.
+        scramble_count may be one int or (with seeds) one int per env.
         Returns the observation of the scrambled cubes."""
         n = self.num_envs
-        if scramble_count <= 0:
+        counts = np.broadcast_to(np.asarray(scramble_count, dtype=np.int64), (n,)) if np.ndim(scramble_count) else None
+        kmax = int(counts.max()) if counts is not None else int(scramble_count)
+        if kmax <= 0 or (counts is not None and int(counts.min()) <= 0):
             # the reference returns an unbound `state` here (UnboundLocalError, cube_env.py:69)
             raise UnboundLocalError("reset(scramble_count=0): the reference has no state to return")
         ops.fill_solved(self.stickers, n, self.cube_size)
         if actions is None and seeds is not None:
             if len(seeds) != n:
                 raise ValueError("need one seed per env")
-            actions = legacy_scramble_actions(seeds, scramble_count, self.action_dim)
+            if counts is None:
+                actions = legacy_scramble_actions(seeds, kmax, self.action_dim)
+            else:
+                actions = np.full((n, kmax), self.action_dim, np.uint8)          # pad with the no-op
+                for k in np.unique(counts):
+                    idx = np.nonzero(counts == k)[0]
+                    actions[idx, :k] = legacy_scramble_actions([seeds[i] for i in idx], int(k), self.action_dim)
+        elif counts is not None:
+            raise ValueError("per-env scramble counts need seeds (or pad explicit actions with the no-op)")
         if actions is not None:
             a = torch.as_tensor(actions, dtype=torch.uint8)
-            if tuple(a.shape) != (n, scramble_count):
-                raise ValueError(f"actions must be [{n}, {scramble_count}]")
-            if int(a.max()) >= self.action_dim:
+            if a.dim() != 2 or a.shape[0] != n:
+                raise ValueError(f"actions must be [{n}, K]")
+            if int(a.max()) > self.action_dim:
                 raise IndexError("action out of range")  # cube_env.py:86,96
-            buf = torch.zeros((scramble_count, _lib.pitch_for(n)), dtype=torch.uint8)
+            k = a.shape[1]
+            buf = torch.full((k, _lib.pitch_for(n)), self.action_dim, dtype=torch.uint8)
             buf[:, :n] = a.t()
-            ops.scramble(self.stickers, n, self.cube_size, scramble_count, actions_in=buf.to(self.device),
+            ops.scramble(self.stickers, n, self.cube_size, k, actions_in=buf.to(self.device),
                          done=self.done, reward=self.reward)
         else:
             self._resets += 1
-            ops.scramble(self.stickers, n, self.cube_size, scramble_count, seed=self.seed, stream_id=self.stream_id,
+            ops.scramble(self.stickers, n, self.cube_size, kmax, seed=self.seed, stream_id=self.stream_id,
                          walk_offset=self._resets * n, done=self.done, reward=self.reward)
         return self._observe()
 
-    def step(self, actions):
+    def step(self, actions, active=None):
         """One face turn per cube.  actions: uint8 tensor [N] on the env's device (anything else is
-        converted).  Returns (obs, reward float32 [N] of +-1.0, done uint8 [N], {}) -- cube_env.py:71-111."""
+        converted and range-checked).  active: optional bool tensor [N]; cubes where it is False get
+        the no-op (they keep their state; used by batched rollouts to park solved cubes).
+        Returns (obs, reward float32 [N] of +-1.0, done uint8 [N], {}) -- cube_env.py:71-111."""
         a = self._actions(actions)
+        if active is not None:
+            a = torch.where(active.to(self.device), a, torch.full_like(a, self.action_dim))
         ops.apply_moves(self.stickers, self.stickers, a, self.num_envs, self.cube_size, self.reward, self.done,
                         self._obs_buf, self._fmt)
         return self._obs_buf, self.reward, self.done, {}

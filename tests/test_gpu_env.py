@@ -180,9 +180,9 @@ def test_vec_env_vs_oracle(mod, oracle, cs, obs):
         assert (_ops.to_aos(ex["child_code"][a], n).cpu().numpy() == cc[:, a]).all()
         assert (_ops.to_aos(ex["children"][a], n).cpu().numpy() == ch[:, a]).all()
     with pytest.raises(IndexError):
-        env.step(np.full(n, A))
+        env.step(np.full(n, A))                                                        # host-converted actions are range-checked
     bad = torch.zeros(n, dtype=torch.uint8, device="cuda")
-    bad[17] = A
+    bad[17] = A + 1                                                                    # (A itself is the no-op)
     env.step(bad)                                                                      # device path cannot raise...
     with pytest.raises(IndexError):
         env.check_actions()                                                            # ...the status word does
@@ -203,3 +203,136 @@ def test_vec_env_seeded_reset_is_reference_reset(mod, golden):
     assert (np.random.get_state()[1] == before).all()
     with pytest.raises(UnboundLocalError):
         env.reset(scramble_count=0)
+
+
+# ------------------------------------------------------------------ no-op, rollouts (N3), MCTS (N2)
+class TinyNet(torch.nn.Module):
+    """DeepCube-shaped stand-in (model.py:7-45) with float64 maths so CPU and GPU agree on every arg-max."""
+
+    def __init__(self, state_dim, action_dim, seed=0):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        d = state_dim[0] * state_dim[1]
+        self.w1 = torch.nn.Parameter(torch.randn(d, 64, generator=g, dtype=torch.float64))
+        self.wp = torch.nn.Parameter(torch.randn(64, action_dim, generator=g, dtype=torch.float64))
+        self.wv = torch.nn.Parameter(torch.randn(64, 1, generator=g, dtype=torch.float64))
+
+    def forward(self, x):
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+        h = torch.nn.functional.elu(x.reshape(x.shape[0], -1).double() @ self.w1)
+        return h @ self.wv, h @ self.wp
+
+    def get_action(self, x, pre_action=None):          # model.py:47-76 restated for the per-cube reference loop
+        order = self.forward(x)[1].sort(descending=True)[1][0]
+        invalid = None if pre_action is None else (pre_action - 1 if pre_action % 2 == 1 else pre_action + 1)
+        return order[1].item() if invalid == order[0] else order[0].item()
+
+    def predict(self, x):                               # model.py:78-91
+        v, p = self.forward(torch.tensor(np.asarray(x)).float())
+        return v.detach().cpu().numpy()[0], torch.softmax(p, -1).detach().cpu().numpy()[0]
+
+
+def test_noop_action_and_active_mask(mod, oracle):
+    for cs, A in ((3, 12), (2, 6)):
+        n = 3000
+        env = mod.VecCubeEnv(n, "cuda", cs, obs=None, seed=3)
+        env.reset(scramble_count=9)
+        before = env.sim_cube.cpu().numpy()
+        acts = np.random.default_rng(2).integers(0, A, n, dtype=np.uint8)
+        active = torch.from_numpy(np.arange(n) % 3 != 0).cuda()
+        env.step(torch.from_numpy(acts).cuda(), active=active)
+        exp = oracle.step(cs, before, acts)[0]
+        keep = (np.arange(n) % 3 == 0)
+        exp[keep] = before[keep]
+        assert (env.sim_cube.cpu().numpy() == exp).all()
+        env.check_actions()                                  # the no-op is not an error
+        env.step(torch.full((n,), A, dtype=torch.uint8, device="cuda"))
+        assert (env.sim_cube.cpu().numpy() == exp).all()
+        env.check_actions()
+        env.step(torch.full((n,), A + 1, dtype=torch.uint8, device="cuda"))
+        with pytest.raises(IndexError):
+            env.check_actions()
+
+
+@pytest.mark.parametrize("mask", [False, True])
+def test_greedy_rollout_matches_per_cube_loop(mod, mask):
+    from oracle.oracle_np import OracleCubeEnv
+    from rubiks_cube_solver_amd.rollout import greedy_rollout
+    net = TinyNet([20, 24], 12, seed=4)
+    seeds, ks, T = list(range(360)), [1 + (i % 3) for i in range(360)], 14
+    env = mod.VecCubeEnv(len(seeds), "cuda", 3, obs="onehot")
+    env.reset(seeds=seeds, scramble_count=ks)
+    res = greedy_rollout(net.cuda(), env, T, mask=mask, sync_every=1)
+    steps = res["solve_step"].cpu().numpy()
+    net.cpu()
+    ref = OracleCubeEnv(None, 3)
+    n_solved = 0
+    for i, (s, k) in enumerate(zip(seeds, ks)):
+        state, pre, solved_at = ref.reset(seed=s, scramble_count=k), None, 0
+        for t in range(1, T + 1):                            # test.py:126-151 / train.py:183-193
+            with torch.no_grad():
+                a = net.get_action(torch.tensor(state).float(), pre if mask else None)
+            if mask:
+                pre = a
+            state, _, done, _ = ref.step(a)
+            if done:
+                solved_at = t
+                break
+        assert steps[i] == solved_at, (i, steps[i], solved_at)
+        n_solved += solved_at > 0
+    assert n_solved >= 2                                      # the parking path was exercised
+    assert (env.is_solved().cpu().numpy().astype(bool) == (steps > 0)).all()
+
+
+def test_solve_percentage_shape(mod):
+    from rubiks_cube_solver_amd.rollout import solve_percentage
+    net = TinyNet([7, 21], 6, seed=1).cuda()
+    pct = solve_percentage(net, 2, 4, 25, 12, device="cuda")
+    assert len(pct) == 4 and all(0.0 <= p <= 100.0 for p in pct)
+
+
+def test_mcts_class_and_batched_mcts(mod, oracle):
+    from rubiks_cube_solver_amd.mcts_batched import MCTS, BatchedMCTS
+    cfg = {"mcts": {"virtual_loss_const": 150, "cpuct": 1.0, "value_min": -10.0, "numMCTSSim": 50}, "test": {"cube_size": 3}}
+    net = TinyNet([20, 24], 12, seed=2)
+    env = mod.make_env(torch.device("cpu"), 3)
+    state = env.reset(seed=3, scramble_count=1)
+    tree = MCTS(net, cfg)
+    actions = tree.train(state, env)                          # depth-1 scramble: the first expansion sees the solved child
+    assert actions is not None and len(actions) == 1
+    chk = oracle.step(3, env.sim_cube[None].astype(np.uint8), np.array(actions[-1:], np.uint8))
+    assert chk[2][0] == 1
+    root = tree.children_and_data[MCTS.key_of(env)]
+    _, cc, cs = oracle.expand(3, env.sim_cube[None].astype(np.uint8))
+    assert [c.tobytes() for c in cc[0]] == root.children and list(cs[0].astype(bool)) == root.done
+    state = env.reset(seed=8, scramble_count=3)
+    tree, found = MCTS(net, cfg), None
+    for _ in range(400):
+        found = tree.train(state, env)
+        if found is not None:
+            break
+    if found is not None:                                     # replay the returned path: it must solve the cube
+        s = env.sim_cube[None].astype(np.uint8)
+        for a in found:
+            s, _, d, _ = oracle.step(3, s, np.array([a], np.uint8))
+        assert d[0] == 1
+    # lockstep search over many roots
+    n = 256
+    venv = mod.VecCubeEnv(n, "cuda", 3, obs=None, seed=21)
+    venv.reset(seeds=list(range(n)), scramble_count=[1 + (i % 2) for i in range(n)])
+    roots = venv.sim_cube.cpu().numpy()
+    bm = BatchedMCTS(net.cuda(), venv.stickers, n, 3)
+    solved = 0
+    for _ in range(20):
+        solved = bm.simulate()
+        if solved == n:
+            break
+    # every depth-1 root is solved by its first expansion; deeper ones depend on the (random) net's guidance
+    assert all(bm.solution[r] is not None and len(bm.solution[r]) == 1 for r in range(0, n, 2)) and solved >= n // 2
+    for r in range(n):
+        if bm.solution[r] is not None:
+            s = roots[r:r + 1]
+            for a in bm.solution[r]:
+                s, _, d, _ = oracle.step(3, s, np.array([a], np.uint8))
+            assert d[0] == 1, r

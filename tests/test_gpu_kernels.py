@@ -328,7 +328,7 @@ def test_bad_action_sets_status(ops, L):
     n = 100
     st = ops.alloc_states(n, 3, "cuda")
     ops.fill_solved(st, n, 3)
-    for bad in (12, 13, 200, 255):
+    for bad in (13, 14, 200, 255):            # 12 is the no-op
         acts = torch.zeros(n, dtype=torch.uint8, device="cuda")
         acts[37] = bad
         ops.apply_moves(st, st, acts, n, 3)
@@ -336,7 +336,7 @@ def test_bad_action_sets_status(ops, L):
         assert L.read_status() == 0
     st2 = ops.alloc_states(n, 2, "cuda")
     ops.fill_solved(st2, n, 2)
-    for bad in (6, 7, 11, 12, 99):
+    for bad in (7, 8, 11, 12, 13, 99):         # 6 is the no-op
         acts = torch.zeros(n, dtype=torch.uint8, device="cuda")
         acts[5] = bad
         ops.apply_moves(st2, st2, acts, n, 2)

@@ -121,16 +121,19 @@ __global__ void __launch_bounds__(BLOCK) k_step(StepArgs a) {
 
 // ----------------------------------------------------------- step + dense one-hot (LDS stage)
 constexpr int kDenseBlock = 256;
-constexpr int kDenseTile = kDenseBlock * 4;  // cubes per workgroup
-constexpr int kDenseTp = kDenseTile + 4;     // LDS row pitch in bytes: 257 dwords -> rows fall on different banks
+// TILE cubes per workgroup (64 | 256 | 1024): the first TILE/4 lanes compute the pack's codes, then
+// all 256 threads stream the dense rows.  Small tiles keep small batches (MCTS leaves) spread over
+// the chip: 4096 cubes are 64 workgroups at TILE = 64 but only 4 at TILE = 1024.
+// LDS row pitch TILE + 4 bytes: rows fall on different banks for the byte reads of dense_write.
 
-template <class T, class E, bool MOVE, bool STORE>
+template <class T, class E, bool MOVE, bool STORE, int TILE>
 __global__ void __launch_bounds__(kDenseBlock) k_step_dense(StepArgs a, E *dense) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds_code[T::SLOTS * kDenseTp];
-    const int64_t tile0 = (int64_t)blockIdx.x * kDenseTile;
+    constexpr int TP = TILE + 4;
+    __shared__ __attribute__((aligned(16))) uint8_t lds_code[T::SLOTS * TP];
+    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
     const uint32_t lo = threadIdx.x * 4;
     const int64_t n0 = tile0 + lo;
-    if (n0 < a.n) {
+    if (lo < TILE && n0 < a.n) {
         Pk<1> s[T::S];
         {
             const uint8_t *row = a.in + tile_off(tile0, a.pitch_in, a.sh_in, T::S);
@@ -160,28 +163,29 @@ __global__ void __launch_bounds__(kDenseBlock) k_step_dense(StepArgs a, E *dense
         Pk<1> c[T::SLOTS];
         encode<T, 1>(s, c);
 #pragma unroll
-        for (int p = 0; p < T::SLOTS; ++p) *reinterpret_cast<uint32_t *>(lds_code + p * kDenseTp + threadIdx.x * 4) = c[p].d[0];
+        for (int p = 0; p < T::SLOTS; ++p) *reinterpret_cast<uint32_t *>(lds_code + p * TP + lo) = c[p].d[0];
     }
     __syncthreads();
     const int64_t left = a.n - tile0;
-    const int ncubes = left < kDenseTile ? (int)left : kDenseTile;
-    dense_write<T, E>(lds_code, kDenseTp, dense + tile0 * (T::R * T::C), ncubes, threadIdx.x, kDenseBlock);
+    const int ncubes = left < TILE ? (int)left : TILE;
+    dense_write<T, E>(lds_code, TP, dense + tile0 * (T::R * T::C), ncubes, threadIdx.x, kDenseBlock);
 }
 
-template <class T, class E>
+template <class T, class E, int TILE>
 __global__ void __launch_bounds__(kDenseBlock) k_code_to_dense(const uint8_t *code, int64_t n, int64_t code_pitch, int shift, E *dense) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds_code[T::SLOTS * kDenseTp];
-    const int64_t tile0 = (int64_t)blockIdx.x * kDenseTile;
-    const int64_t n0 = tile0 + threadIdx.x * 4;
-    if (n0 < n) {
-        const uint8_t *row = code + tile_off(tile0, code_pitch, shift, T::SLOTS) + threadIdx.x * 4;
+    constexpr int TP = TILE + 4;
+    __shared__ __attribute__((aligned(16))) uint8_t lds_code[T::SLOTS * TP];
+    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
+    const uint32_t lo = threadIdx.x * 4;
+    if (lo < TILE && tile0 + lo < n) {
+        const uint8_t *row = code + tile_off(tile0, code_pitch, shift, T::SLOTS) + lo;
 #pragma unroll
-        for (int p = 0; p < T::SLOTS; ++p) { *reinterpret_cast<uint32_t *>(lds_code + p * kDenseTp + threadIdx.x * 4) = ld<1, false>(row).d[0]; row += code_pitch; }
+        for (int p = 0; p < T::SLOTS; ++p) { *reinterpret_cast<uint32_t *>(lds_code + p * TP + lo) = ld<1, false>(row).d[0]; row += code_pitch; }
     }
     __syncthreads();
     const int64_t left = n - tile0;
-    const int ncubes = left < kDenseTile ? (int)left : kDenseTile;
-    dense_write<T, E>(lds_code, kDenseTp, dense + tile0 * (T::R * T::C), ncubes, threadIdx.x, kDenseBlock);
+    const int ncubes = left < TILE ? (int)left : TILE;
+    dense_write<T, E>(lds_code, TP, dense + tile0 * (T::R * T::C), ncubes, threadIdx.x, kDenseBlock);
 }
 
 // ---------------------------------------------------------------------------- expand
@@ -496,14 +500,35 @@ int dispatch_step(const StepArgs &a, hipStream_t st) {
     }
 }
 
-template <class T, bool MOVE, bool STORE>
-int launch_dense(const StepArgs &a, void *onehot, int fmt, hipStream_t st) {
-    const int64_t blocks = (a.n + kDenseTile - 1) / kDenseTile;
+inline int dense_tile(int64_t n) { return n >= ((int64_t)1 << 19) ? 1024 : n >= ((int64_t)1 << 17) ? 256 : 64; }
+
+template <class T, bool MOVE, bool STORE, int TILE>
+int launch_dense_t(const StepArgs &a, void *onehot, int fmt, hipStream_t st) {
+    const int64_t blocks = (a.n + TILE - 1) / TILE;
     if (blocks > 0x7fffffff) return fail(RC_EINVAL, "too many cubes for one launch%s");
     const dim3 g((unsigned)blocks), b(kDenseBlock);
-    if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_step_dense<T, uint8_t, MOVE, STORE>), g, b, 0, st, a, static_cast<uint8_t *>(onehot));
-    else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_step_dense<T, uint16_t, MOVE, STORE>), g, b, 0, st, a, static_cast<uint16_t *>(onehot));
-    else hipLaunchKernelGGL((k_step_dense<T, float, MOVE, STORE>), g, b, 0, st, a, static_cast<float *>(onehot));
+    if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_step_dense<T, uint8_t, MOVE, STORE, TILE>), g, b, 0, st, a, static_cast<uint8_t *>(onehot));
+    else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_step_dense<T, uint16_t, MOVE, STORE, TILE>), g, b, 0, st, a, static_cast<uint16_t *>(onehot));
+    else hipLaunchKernelGGL((k_step_dense<T, float, MOVE, STORE, TILE>), g, b, 0, st, a, static_cast<float *>(onehot));
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
+template <class T, bool MOVE, bool STORE>
+int launch_dense(const StepArgs &a, void *onehot, int fmt, hipStream_t st) {
+    switch (dense_tile(a.n)) {
+        case 1024: return launch_dense_t<T, MOVE, STORE, 1024>(a, onehot, fmt, st);
+        case 256: return launch_dense_t<T, MOVE, STORE, 256>(a, onehot, fmt, st);
+        default: return launch_dense_t<T, MOVE, STORE, 64>(a, onehot, fmt, st);
+    }
+}
+
+template <class T, int TILE>
+int launch_code_to_dense(const uint8_t *code, int64_t n, int64_t code_pitch, int sh, void *onehot, int fmt, hipStream_t st) {
+    const dim3 g((unsigned)((n + TILE - 1) / TILE)), b(kDenseBlock);
+    if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_code_to_dense<T, uint8_t, TILE>), g, b, 0, st, code, n, code_pitch, sh, static_cast<uint8_t *>(onehot));
+    else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_code_to_dense<T, uint16_t, TILE>), g, b, 0, st, code, n, code_pitch, sh, static_cast<uint16_t *>(onehot));
+    else hipLaunchKernelGGL((k_code_to_dense<T, float, TILE>), g, b, 0, st, code, n, code_pitch, sh, static_cast<float *>(onehot));
     RC_HIP(hipGetLastError());
     return RC_OK;
 }
@@ -517,12 +542,14 @@ int check_fmt(void *onehot, int fmt, int64_t code_pitch, int64_t n, int *sh_code
     return RC_OK;
 }
 
-int parts_for(int64_t groups, int A) {
-    // enough wave-items to cover 256 CUs a few times over; parts must divide the work evenly enough
-    const int64_t want = 2048;
+int parts_for(int64_t groups, int A, int64_t want = 2048) {
+    // enough wave-items to cover 256 CUs a few times over; parts must divide A (1,2,3,4,6,12 | 1,2,3,6).
+    // rc_set_variant: (v / 1000) % 100 forces the value (benchmarks).
+    const int forced = (g_variant / 1000) % 100;
     int parts = 1;
-    while (parts < A && groups * parts < want) ++parts;
-    while (A % parts) ++parts;  // 1,2,3,4,6,12 | 1,2,3,6
+    if (forced >= 1 && forced <= A) parts = forced;
+    else while (parts < A && groups * parts < want) ++parts;
+    while (A % parts) ++parts;
     return parts;
 }
 
@@ -651,12 +678,11 @@ int rc_onehot_from_code(const uint8_t *code, int64_t n, int64_t code_pitch, int 
     if (n == 0) return RC_OK;
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
-        const dim3 g((unsigned)((n + kDenseTile - 1) / kDenseTile)), b(kDenseBlock);
-        if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_code_to_dense<T, uint8_t>), g, b, 0, S(stream), code, n, code_pitch, sh, static_cast<uint8_t *>(onehot));
-        else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_code_to_dense<T, uint16_t>), g, b, 0, S(stream), code, n, code_pitch, sh, static_cast<uint16_t *>(onehot));
-        else hipLaunchKernelGGL((k_code_to_dense<T, float>), g, b, 0, S(stream), code, n, code_pitch, sh, static_cast<float *>(onehot));
-        RC_HIP(hipGetLastError());
-        return RC_OK;
+        switch (dense_tile(n)) {
+            case 1024: return launch_code_to_dense<T, 1024>(code, n, code_pitch, sh, onehot, fmt, S(stream));
+            case 256: return launch_code_to_dense<T, 256>(code, n, code_pitch, sh, onehot, fmt, S(stream));
+            default: return launch_code_to_dense<T, 64>(code, n, code_pitch, sh, onehot, fmt, S(stream));
+        }
     });
 }
 
@@ -702,8 +728,10 @@ int rc_adi_generate(uint64_t seed, uint64_t stream_id, int64_t walk_offset, int6
         const int V = 1;
         const int64_t groups = (n_walks + kWave * 4 * V - 1) / (kWave * 4 * V);
         const bool any_child = children || child_code || child_solved;
+        // sticker children are byte-bound: split them over many waves; code-only expansion is VALU-bound
+        // (every part re-encodes the parent), measured best at 2 parts for 100k walks
         AdiArgs a{seed, stream_id, walk_offset, n_walks, pitch, n_walks <= pitch ? 1 : (n_walks + pitch - 1) / pitch, depth,
-                  any_child ? parts_for(groups, T::A) : 1, sh, actions_in, actions_out, parents, parent_code, children, child_code, child_solved};
+                  any_child ? parts_for(groups, T::A, children ? 2048 : 700) : 1, sh, actions_in, actions_out, parents, parent_code, children, child_code, child_solved};
         const dim3 g((unsigned)(groups * a.parts)), b(kWave);
         if (parent_code || child_code) hipLaunchKernelGGL((k_adi<T, 1, true>), g, b, 0, S(stream), a);
         else hipLaunchKernelGGL((k_adi<T, 1, false>), g, b, 0, S(stream), a);

@@ -179,6 +179,28 @@ def test_apply_moves_dense_onehot(ops, L, oracle, cs, fmt_name, n, pitch):
     assert torch.equal(oh, oh3)
 
 
+@pytest.mark.parametrize("n", [150_000, 600_000])          # dense tile sizes 256 and 1024 (small n uses 64)
+def test_dense_onehot_large_tiles(ops, L, n):
+    st = ops.alloc_states(n, 3, "cuda")
+    ops.fill_solved(st, n, 3)
+    ops.scramble(st, n, 3, 13, seed=n)
+    code = ops.alloc_code(n, 3, "cuda")
+    ops.encode(st, n, 3, code, L.FMT_CODE)
+    want = torch.nn.functional.one_hot(ops.to_aos(code, n).long(), 24).to(torch.uint8)     # [n, 20, 24]
+    for fmt in (L.FMT_U8, L.FMT_F32):
+        oh = torch.empty((n, 20, 24), dtype=L.dense_dtype(fmt), device="cuda")
+        ops.encode(st, n, 3, oh, fmt)
+        assert torch.equal(oh.to(torch.uint8), want)
+        oh.fill_(3)
+        ops.onehot_from_code(code, n, 3, oh)
+        assert torch.equal(oh.to(torch.uint8), want)
+    acts = torch.randint(0, 12, (n,), dtype=torch.uint8, device="cuda")
+    st2, oh2 = torch.empty_like(st), torch.empty((n, 20, 24), dtype=torch.float16, device="cuda")
+    ops.apply_moves(st, st2, acts, n, 3, None, None, oh2, L.FMT_F16)
+    ops.encode(st2, n, 3, code, L.FMT_CODE)
+    assert torch.equal(oh2.to(torch.uint8), torch.nn.functional.one_hot(ops.to_aos(code, n).long(), 24).to(torch.uint8))
+
+
 def test_golden_walks_on_gpu(ops, L, golden):
     """G3 replayed step by step through rc_apply_moves: stickers, one-hot column, done, reward."""
     g = golden("walks_333")

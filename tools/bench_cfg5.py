@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""BASELINE.json config 5: MCTS batched expand, 4096 leaves x 12 children per step, interleaved with
+the value-net forward on [4096, 480] fp32 (latency-bound: report microseconds and overlap, not GB/s).
+
+The net is a random-init stand-in with the reference's architecture (model.py:7-45 with
+config.yaml hidden_dim [1024, 256, 128]): the product consumes the caller's model unchanged."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from torch import nn
+
+from rubiks_cube_solver_amd import _lib, ops
+
+
+class DeepCubeStandIn(nn.Module):
+    def __init__(self, state_dim=(20, 24), action_dim=12, hidden=(1024, 256, 128)):
+        super().__init__()
+        d = state_dim[0] * state_dim[1]
+        self.encoder_net = nn.Sequential(nn.Flatten(), nn.Linear(d, hidden[0]), nn.ELU(), nn.Linear(hidden[0], hidden[1]), nn.ELU())
+        self.policy_net = nn.Sequential(nn.Linear(hidden[1], hidden[2]), nn.ELU(), nn.Linear(hidden[2], action_dim))
+        self.value_net = nn.Sequential(nn.Linear(hidden[1], hidden[2]), nn.ELU(), nn.Linear(hidden[2], 1))
+
+    def forward(self, x):
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+        h = self.encoder_net(x)
+        return self.value_net(h), self.policy_net(h)
+
+
+def timeit(fn, iters=200, warm=20):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+@torch.no_grad()
+def main():
+    n, cs, dev = 4096, 3, torch.device("cuda")
+    model = DeepCubeStandIn().to(dev).eval()
+    leaves = ops.alloc_states(n, cs, dev)
+    ops.fill_solved(leaves, n, cs)
+    ops.scramble(leaves, n, cs, 20, seed=7)
+    ex = ops.expand_buffers(n, cs, dev, children=True, codes=True)
+    pitch = ex["children"].shape[-1]
+    code = ops.alloc_code(n, cs, dev)
+    onehot = torch.empty((n, 20, 24), dtype=torch.float32, device=dev)
+    side = torch.cuda.Stream(dev)
+
+    def expand():
+        ops.expand_children(leaves, n, cs, ex["children"], ex["child_solved"], ex["child_code"], pitch=pitch)
+
+    def expand_flags_codes():
+        ops.expand_children(leaves, n, cs, None, ex["child_solved"], ex["child_code"], pitch=pitch)
+
+    def encode():
+        ops.encode(leaves, n, cs, onehot, _lib.FMT_F32)
+
+    def forward():
+        return model(onehot)
+
+    def serial():
+        expand(); encode(); forward()
+
+    def overlapped():
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            expand()
+        encode(); forward()
+        torch.cuda.current_stream().wait_stream(side)
+
+    res = {
+        "leaves": n, "children_per_step": n * 12,
+        "expand_stickers_codes_flags_us": timeit(expand),
+        "expand_codes_flags_us": timeit(expand_flags_codes),
+        "encode_dense_f32_us": timeit(encode),
+        "forward_us": timeit(forward),
+        "serial_step_us": timeit(serial),
+        "overlapped_step_us": timeit(overlapped),
+    }
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream(dev)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            serial()
+    torch.cuda.current_stream().wait_stream(s)
+    try:
+        with torch.cuda.graph(g):
+            serial()
+        res["hipgraph_serial_step_us"] = timeit(g.replay)
+    except Exception as e:  # capture of foreign launches may be refused by the runtime
+        res["hipgraph_serial_step_us"] = None
+        res["hipgraph_error"] = str(e)[:200]
+    try:                                     # fork/join inside one graph: expansion branch || encode + forward branch
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            overlapped()
+        res["hipgraph_overlapped_step_us"] = timeit(g2.replay)
+    except Exception as e:
+        res["hipgraph_overlapped_step_us"] = None
+        res["hipgraph_overlap_error"] = str(e)[:200]
+    hidden = res["serial_step_us"] - res["overlapped_step_us"]
+    res["overlap_hidden_us"] = hidden
+    res["overlap_fraction_of_expand"] = hidden / res["expand_stickers_codes_flags_us"]
+    print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in res.items()}))
+
+
+if __name__ == "__main__":
+    main()

@@ -89,6 +89,19 @@ def main():
             out.append(dict(k=f"adi_100k_x30_codes_{tag}", ms=t * 1e3, Gunits=W * D / t / 1e9,
                             GBps=(54 + 1 + 12 + 13 * 20) * W * D / t / 1e9))
             del bufs
+    if "adiparts" in which:
+        W, D = 100_000, 30
+        for parts in (1, 2, 3, 4, 6, 12):
+            L.rc_set_variant(parts * 1000)
+            pt, bufs = ops.adi_buffers(W, D, 3, "cuda", parents=True, parent_code=True, child_code=True)
+            t = timeit(lambda: ops.adi_generate(W, D, 3, pt, "cuda", seed=2024, **bufs), iters=5, warm=2)
+            out.append(dict(k=f"adi_codes_parts{parts}", ms=t * 1e3, Gunits=W * D / t / 1e9))
+            del bufs
+            pt, bufs = ops.adi_buffers(W, D, 3, "cuda", parents=True, children=True)
+            t = timeit(lambda: ops.adi_generate(W, D, 3, pt, "cuda", seed=2024, **bufs), iters=5, warm=2)
+            out.append(dict(k=f"adi_stickers_parts{parts}", ms=t * 1e3, Gunits=W * D / t / 1e9, GBps=715 * W * D / t / 1e9))
+            del bufs
+        L.rc_set_variant(0)
     if "expand" in which:
         for m in (4096, 1 << 20):
             src = ops.alloc_states(m, 3, "cuda")

@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--extras", action="store_true", help="also time fused reward / code / ADI variants (outside the timed region)")
+    ap.add_argument("--backend", default="nccl", help="process-group backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -82,11 +83,16 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count())      # one rank per GPU (rehearsals may share one)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)  # reporting only: barrier + max of elapsed time
+        # reporting only (barrier + MAX of elapsed time): the env path itself has no collective
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from rubiks_cube_solver_amd import _lib, ops  # raises if librubikhip.so is missing: no fallback
 
@@ -123,7 +129,7 @@ def main():
     dev_ms = e0.elapsed_time(e1)                                     # HIP events on the launch stream
     assert _lib.read_status(dev) == 0
     if world > 1:
-        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dev_ms = float(t[0]), float(t[1])
 
@@ -146,7 +152,14 @@ def main():
         extras["step_reward_done"] = {"steps_per_s": n / t, "GBps": 114 * n / t / 1e9}
         t = timed(lambda: (ops.apply_moves(bufs[0], bufs[1], acts, n, CUBE, rew, done, code, _lib.FMT_CODE), bufs.reverse()))
         extras["step_reward_done_code"] = {"steps_per_s": n / t, "GBps": 134 * n / t / 1e9}
-        m = 1 << 20
+        m = 1 << 20                                                  # BASELINE config 2: batch 1M, apply_move + reward
+        a1, b1 = ops.alloc_states(m, CUBE, dev), ops.alloc_states(m, CUBE, dev)
+        ops.fill_solved(a1, m, CUBE)
+        ops.scramble(a1, m, CUBE, 20, seed=1234)
+        pp = [a1, b1]
+        t = timed(lambda: (ops.apply_moves(pp[0], pp[1], acts, m, CUBE, rew, done), pp.reverse()), iters=200)
+        extras["cfg2_step_reward_done_1M"] = {"steps_per_s": m / t, "GBps": 114 * m / t / 1e9, "launch_us": t * 1e6,
+                                              "note": "226 MB ping-pong working set fits the 256 MB Infinity Cache"}
         oh = torch.empty((m, 20, 24), dtype=torch.float32, device=dev)
         t = timed(lambda: ops.apply_moves(a, b, acts, m, CUBE, rew, done, oh, _lib.FMT_F32), iters=10)
         extras["step_dense_f32_1M"] = {"steps_per_s": m / t, "GBps": (114 + 1920) * m / t / 1e9}

@@ -13,7 +13,7 @@
  *     (cube_size 3) or 24 (cube_size 2) rows, in TILES of `pitch` cubes:
  *         sticker s of cube n lives at st[(n / pitch) * S * pitch + s * pitch + n % pitch].
  *     One tile (pitch >= n_cubes, pitch % 16 == 0) is plain SoA, st[s * pitch + n].  Several
- *     tiles need a power-of-two pitch >= 1024; 16384 measured best on MI355X at 4M cubes
+ *     tiles need a power-of-two pitch >= 1024; 16384-32768 measured best on MI355X at 4M cubes
  *     (+12..24 % HBM throughput over one 4M-wide tile: every wave's 54 row segments then sit
  *     within 54 * pitch bytes).  RC_FMT_CODE buffers are tiled the same way with SLOTS rows.
  *     Buffers described as "plain" below are one tile.  Base pointers are 16-byte aligned.

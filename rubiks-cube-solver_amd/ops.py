@@ -6,7 +6,7 @@ validates its tensors and forwards raw pointers + the current HIP stream to libr
 State layout (include/rubikhip.h "State layout"): uint8 tensor [tiles, S, pitch] -- structure of
 arrays in tiles: one row per sticker, one column per cube, `pitch` cubes per tile; cube n sits in
 tile n // pitch, column n % pitch.  A 2-D [S, pitch] tensor is the one-tile case.  Buffers with
-several tiles need a power-of-two pitch >= 1024 (DEFAULT_TILE = 16384 measured best on MI355X).
+several tiles need a power-of-two pitch >= 1024 (DEFAULT_TILE = 32768 measured best on MI355X).
 Compact code buffers [tiles, SLOTS, pitch] follow the same rule.  Expansion / ADI outputs are
 one-tile ("plain") buffers.
 """
@@ -28,7 +28,7 @@ def _size(cube_size):
     return N_STICKERS[cube_size], ACTION_DIM[cube_size], N_SLOTS[cube_size]
 
 
-DEFAULT_TILE = 16384
+DEFAULT_TILE = 32768
 
 
 def _rows(t, rows, n, what):

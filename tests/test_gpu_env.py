@@ -150,7 +150,7 @@ def test_adi_samples_device_rng_and_gpu_model(mod, oracle, golden):
 @pytest.mark.parametrize("cs", [3, 2])
 @pytest.mark.parametrize("obs", ["onehot", "code", None])
 def test_vec_env_vs_oracle(mod, oracle, cs, obs):
-    n = 20000
+    n = 40000
     A = 12 if cs == 3 else 6
     env = mod.VecCubeEnv(n, "cuda", cs, obs=obs, onehot_dtype=torch.float16, seed=5, stream_id=1)
     assert env.stickers.shape[0] > 1                                                   # tiled buffer

@@ -13,8 +13,8 @@ using T = Cube3;
 struct Args { const uint8_t *in; uint8_t *out; const uint8_t *act; uint8_t *done; int64_t n, pitch, tile; };
 
 // address of row i for the lane: plain SoA (tile == 0) or tiled SoA [n/tile][S][tile]
-template <int V, bool MOVE, bool NT, int BLOCK, bool TILED>
-__global__ void __launch_bounds__(BLOCK) k_step(Args a) {
+template <int V, bool MOVE, bool NT, int BLOCK, bool TILED, bool INPLACE = false, int WPE = 1>
+__global__ void __launch_bounds__(BLOCK, WPE) k_step(Args a) {
     const int64_t g0 = (int64_t)blockIdx.x * (BLOCK * 4 * V);
     const uint32_t lo = threadIdx.x * (4 * V);
     const int64_t n0 = g0 + lo;
@@ -30,10 +30,12 @@ __global__ void __launch_bounds__(BLOCK) k_step(Args a) {
         const Pk<V> act = ld<V, false>(a.act + n0);
         Pk<V> m[T::A];
         action_masks<T, V>(act, m);
+        {
         Pk<V> o[T::S];
         apply_move<T, V>(s, m, o);
 #pragma unroll
         for (int i = 0; i < T::S; ++i) s[i] = o[i];
+        }
     }
     { uint8_t *row = a.out + base;
 #pragma unroll
@@ -130,23 +132,28 @@ int main(int argc, char **argv) {
         const int64_t blocks = n / (BLOCK * 4 * V); \
         double t = timeit([&] { a.in = buf[0]; a.out = buf[1]; hipLaunchKernelGGL((k_step<V, MOVE, NT, BLOCK, TILED>), dim3(blocks), dim3(BLOCK), 0, 0, a); std::swap(buf[0], buf[1]); }); \
         report(NAME, t, MOVE ? bytes : cbytes); }
-    for (int64_t nn : {(int64_t)1 << 22, (int64_t)1 << 20}) {
-        const int64_t n = nn;
+    {
+        const int64_t n = (int64_t)1 << 22;
         const double bytes = 110.0 * n, cbytes = 108.0 * n;
-        auto report = [&](const char *name, double t, double by) { printf("n=%-8lld %-40s %8.2f us  %7.1f GB/s  %6.2f Gsteps/s\n", (long long)n, name, t * 1e6, by / t / 1e9, n / t / 1e9); fflush(stdout); };
-        RUN(2, false, true, 64, false, 0, "rowcopy V2 b64 nt plain");
-        RUN(2, true, false, 64, false, 0, "step V2 b64 plain");
-        RUN(2, true, true, 64, false, 0, "step V2 b64 nt plain");
-        RUN(1, true, true, 64, false, 0, "step V1 b64 nt plain");
-        RUN(4, true, true, 64, false, 0, "step V4 b64 nt plain");
-        for (int64_t tile : {1024, 4096, 16384, 65536, 262144, 1048576}) {
-            char nm[64];
-            snprintf(nm, 64, "rowcopy V2 nt tiled%lld", (long long)tile); RUN(2, false, true, 64, true, tile, nm);
-            snprintf(nm, 64, "step V2 tiled%lld", (long long)tile); RUN(2, true, false, 64, true, tile, nm);
-            snprintf(nm, 64, "step V2 nt tiled%lld", (long long)tile); RUN(2, true, true, 64, true, tile, nm);
-            snprintf(nm, 64, "step V1 nt tiled%lld", (long long)tile); RUN(1, true, true, 64, true, tile, nm);
-            snprintf(nm, 64, "step V2 nt b128 tiled%lld", (long long)tile); RUN(2, true, true, 128, true, tile, nm);
-            snprintf(nm, 64, "step V2 nt b256 tiled%lld", (long long)tile); RUN(2, true, true, 256, true, tile, nm);
+        auto report = [&](const char *name, double t, double by) { printf("%-40s %8.2f us  %7.1f GB/s  %6.2f Gsteps/s\n", name, t * 1e6, by / t / 1e9, n / t / 1e9); fflush(stdout); };
+#define RUNI(V, INP, WPE, NAME) { \
+        Args a{buf[0], buf[1], act, done, n, pitch, 32768}; \
+        const int64_t blocks = n / (64 * 4 * V); \
+        double t = timeit([&] { a.in = buf[0]; a.out = buf[1]; hipLaunchKernelGGL((k_step<V, true, true, 64, true, INP, WPE>), dim3(blocks), dim3(64), 0, 0, a); std::swap(buf[0], buf[1]); }); \
+        report(NAME, t, bytes); }
+        for (int rep = 0; rep < 2; ++rep) {
+            RUN(2, false, true, 64, true, 32768, "rowcopy V2 nt tiled32768");
+            RUN(4, false, true, 64, true, 32768, "rowcopy V4 nt tiled32768");
+            RUN(1, true, true, 64, true, 32768, "step V1 nt tiled32768");
+            RUN(2, true, true, 64, true, 32768, "step V2 nt tiled32768");
+            RUN(4, true, true, 64, true, 32768, "step V4 nt tiled32768");
+            RUNI(1, true, 6, "step V1 inplace wpe6");
+            RUNI(2, true, 3, "step V2 inplace wpe3");
+            RUNI(2, true, 4, "step V2 inplace wpe4");
+            RUNI(4, true, 2, "step V4 inplace wpe2");
+            RUNI(2, false, 3, "step V2 outofplace wpe3");
+            RUNI(2, false, 4, "step V2 outofplace wpe4");
+            RUNI(4, false, 2, "step V4 outofplace wpe2");
         }
     }
     return 0;

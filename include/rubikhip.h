@@ -67,8 +67,9 @@ extern "C" {
 /* Library / ABI version (major*100 + minor). */
 int rc_version(void);
 
-/* Select `device` for the calling thread's later calls and make the code object resident.
- * Idempotent.  Replaces: importing py333 (module-level table construction,
+/* Check that `device` is a gfx950 GPU, make the code object resident there and clear its status
+ * word.  Idempotent; the caller's current device is not changed (kernels run on the device of the
+ * stream / current device the caller set, one process per GPU).  Replaces: importing py333 (module-level table construction,
  * gym-cube/gym_cube/envs/assets/py333.py:41-198). */
 int rc_init(int device);
 

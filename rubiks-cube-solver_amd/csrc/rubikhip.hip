@@ -17,7 +17,6 @@
 
 #include <cstdio>
 #include <cstring>
-#include <mutex>
 
 #include "../../include/rubikhip.h"
 #include "rc_device.h"
@@ -568,15 +567,19 @@ int rc_set_variant(int variant) {
 }
 
 int rc_init(int device) {
-    int count = 0;
+    int count = 0, prev = 0;
     RC_HIP(hipGetDeviceCount(&count));
     if (device < 0 || device >= count) return fail(RC_ENODEV, "no such HIP device%s");
-    RC_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
     RC_HIP(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(RC_ENODEV, "librubikhip is built for gfx950 only, device is %s", prop.gcnArchName);
+    // clear the device's status word; the caller's current device is left as it was
+    RC_HIP(hipGetDevice(&prev));
+    RC_HIP(hipSetDevice(device));
     uint32_t zero = 0;
-    RC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_status), &zero, sizeof zero));
+    const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_status), &zero, sizeof zero);
+    RC_HIP(hipSetDevice(prev));
+    RC_HIP(e);
     return RC_OK;
 }
 

@@ -47,6 +47,7 @@ class CubeEnv:
         self._vec = _backend
         self._sim_cache = None
         self._cube_cache = None
+        self._fast = None  # (device result buffer, pinned host mirror, pinned action) for the one-copy step path
         self.init_state()
 
     # ------------------------------------------------------------------ state attributes
@@ -108,11 +109,32 @@ class CubeEnv:
         names = self.action_to_sim_action[self.cube_size]
         sim_action = names[action]  # IndexError / TypeError exactly like the reference's list lookup
         idx = names.index(sim_action)  # moveInds, py333.py:41-44,221
-        obs, reward, done, _ = self._vec.step(torch.tensor([idx], dtype=torch.uint8))
+        if hasattr(self._vec, "stickers"):
+            onehot, solved = self._step_device(idx)
+        else:  # test-only backends
+            obs, _, done, _ = self._vec.step(torch.tensor([idx], dtype=torch.uint8))
+            onehot, solved = obs[0].cpu().numpy(), bool(done[0].item())
         self._sim_cache = None
-        self._cube_cache = self._typed(obs[0])
-        solved = bool(done[0].item())
+        self._cube_cache = onehot.astype(np.int64) if self.cube_size == 3 else onehot.astype(np.float64)
         return self._cube_cache, (1.0 if solved else -1.0), solved, {}
+
+    def _step_device(self, idx):
+        """One launch, one small upload and ONE download: the dense uint8 one-hot and the done flag share a
+        512-byte device buffer ([0:R*C] one-hot, [496] done)."""
+        v = self._vec
+        R, C = self.state_dim
+        if self._fast is None:
+            dev_buf = torch.zeros(512, dtype=torch.uint8, device=v.device)
+            self._fast = (dev_buf, torch.zeros(512, dtype=torch.uint8).pin_memory(), torch.zeros(16, dtype=torch.uint8).pin_memory(),
+                          torch.zeros(16, dtype=torch.uint8, device=v.device))
+        dev_buf, host_buf, host_act, dev_act = self._fast
+        host_act[0] = idx
+        dev_act.copy_(host_act, non_blocking=True)
+        ops.apply_moves(v.stickers, v.stickers, dev_act, 1, self.cube_size, None, dev_buf[496:512], dev_buf[:R * C].view(1, R, C), _lib.FMT_U8)
+        host_buf.copy_(dev_buf, non_blocking=True)
+        torch.cuda.current_stream(v.device).synchronize()
+        h = host_buf.numpy()
+        return h[:R * C].reshape(R, C), bool(h[496])
 
     def sim_state_to_state(self, sim_state):
         """One-hot of an arbitrary sticker vector (cube_env.py:132-152)."""
@@ -207,8 +229,10 @@ class CubeEnv:
         for k, v in self.__dict__.items():
             if k == "_vec":
                 other._vec = self._vec.clone()
-            elif k in ("device",):
+            elif k == "device":
                 other.device = self.device
+            elif k == "_fast":
+                other._fast = None  # re-created lazily; buffers are not shared between copies
             else:
                 setattr(other, k, copy.deepcopy(v, memo))
         return other

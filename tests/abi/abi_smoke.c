@@ -1,0 +1,52 @@
+/* Plain-C consumer of librubikhip.so: shows the ABI needs nothing but pointers, sizes and a stream.
+ * Built by tests/test_abi_c.py with gcc (no hipcc, no C++, no Python types).  Checks KAT-A of
+ * R U R' U' from solved, plus U then U' (reward -1 / +1). */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rubikhip.h"
+
+#define CK(x) do { if ((x) != hipSuccess) { fprintf(stderr, "HIP failure line %d\n", __LINE__); return 2; } } while (0)
+#define RC(x) do { if ((x) != RC_OK) { fprintf(stderr, "rc failure line %d: %s\n", __LINE__, rc_last_error()); return 3; } } while (0)
+
+int main(void) {
+    const int64_t n = 5, pitch = 256;
+    uint8_t *st, *act, *done, host[54 * 256], hdone[8], hact[16];
+    float *reward, hrew[8];
+    if (rc_version() < 100) return 1;
+    RC(rc_init(0));
+    CK(hipMalloc((void **)&st, 54 * pitch)); CK(hipMalloc((void **)&act, 16)); CK(hipMalloc((void **)&done, 16));
+    CK(hipMalloc((void **)&reward, 16 * sizeof(float)));
+    RC(rc_fill_solved(st, n, pitch, 3, NULL));
+    const uint8_t seq[4] = {4, 0, 5, 1};                       /* R U R' U' */
+    for (int k = 0; k < 4; ++k) {
+        memset(hact, seq[k], sizeof hact);
+        CK(hipMemcpy(act, hact, 16, hipMemcpyHostToDevice));
+        RC(rc_apply_moves(st, st, act, n, pitch, pitch, 3, reward, done, NULL, RC_FMT_NONE, 0, NULL));
+    }
+    CK(hipMemcpy(host, st, 54 * pitch, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hrew, reward, sizeof hrew, hipMemcpyDeviceToHost));
+    const char *kat = "004002002110511011223220222331333333544444444511555555";
+    for (int c = 0; c < n; ++c)
+        for (int s = 0; s < 54; ++s)
+            if (host[s * pitch + c] != kat[s] - '0') { fprintf(stderr, "KAT-A mismatch cube %d sticker %d\n", c, s); return 4; }
+    if (hrew[0] != -1.0f) return 5;
+    RC(rc_fill_solved(st, n, pitch, 3, NULL));
+    memset(hact, 0, sizeof hact); CK(hipMemcpy(act, hact, 16, hipMemcpyHostToDevice));
+    RC(rc_apply_moves(st, st, act, n, pitch, pitch, 3, reward, done, NULL, RC_FMT_NONE, 0, NULL));
+    CK(hipMemcpy(hrew, reward, sizeof hrew, hipMemcpyDeviceToHost)); CK(hipMemcpy(hdone, done, 8, hipMemcpyDeviceToHost));
+    if (hrew[2] != -1.0f || hdone[2] != 0) return 6;
+    memset(hact, 1, sizeof hact); CK(hipMemcpy(act, hact, 16, hipMemcpyHostToDevice));
+    RC(rc_apply_moves(st, st, act, n, pitch, pitch, 3, reward, done, NULL, RC_FMT_NONE, 0, NULL));
+    CK(hipMemcpy(hrew, reward, sizeof hrew, hipMemcpyDeviceToHost)); CK(hipMemcpy(hdone, done, 8, hipMemcpyDeviceToHost));
+    if (hrew[2] != 1.0f || hdone[2] != 1) return 7;
+    uint32_t status = 99;
+    RC(rc_read_status(&status, NULL));
+    if (status != 0) return 8;
+    if (rc_fill_solved(NULL, 1, 256, 3, NULL) != RC_EINVAL || strlen(rc_last_error()) == 0) return 9;
+    puts("abi_smoke ok");
+    return 0;
+}

@@ -89,6 +89,38 @@ def main():
             out.append(dict(k=f"adi_100k_x30_codes_{tag}", ms=t * 1e3, Gunits=W * D / t / 1e9,
                             GBps=(54 + 1 + 12 + 13 * 20) * W * D / t / 1e9))
             del bufs
+    if "facade" in which:
+        import time
+        import numpy as np
+        import rubiks_cube_solver_amd as rc
+        env = rc.make_env(torch.device("cpu"), 3)
+        env.reset(seed=1, scramble_count=20)
+        acts = np.random.default_rng(0).integers(0, 12, 2000)
+        for a_ in acts[:100]:
+            env.step(int(a_))
+        t0 = time.perf_counter()
+        for a_ in acts:
+            env.step(int(a_))
+        dt = (time.perf_counter() - t0) / len(acts)
+        out.append(dict(k="facade_batch1_step", us=dt * 1e6, steps_per_s=1 / dt))
+        m = 1 << 20
+        venv = rc.VecCubeEnv(m, "cuda", 3, obs="code")
+        venv.reset(scramble_count=20)
+        ha = torch.from_numpy(np.random.default_rng(1).integers(0, 12, m, dtype=np.uint8)).pin_memory()
+        hd = torch.empty(m, dtype=torch.uint8).pin_memory()
+        hcode = torch.empty(venv._obs_buf.shape, dtype=torch.uint8).pin_memory()
+        def pcie_step():
+            o, r, d, _ = venv.step(ha.to("cuda", non_blocking=True))
+            hd.copy_(d, non_blocking=True)
+            hcode.copy_(o, non_blocking=True)
+            torch.cuda.synchronize()
+        for _ in range(3):
+            pcie_step()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            pcie_step()
+        dt = (time.perf_counter() - t0) / 20
+        out.append(dict(k="vec_1M_step_pcie_inclusive(actions H2D, done+code D2H)", ms=dt * 1e3, Gsteps=m / dt / 1e9))
     if "adiparts" in which:
         W, D = 100_000, 30
         for parts in (1, 2, 3, 4, 6, 12):

@@ -12,8 +12,9 @@ def run(fn, iters):
     s1.record(); torch.cuda.synchronize()
     return s0.elapsed_time(s1) / iters
 variants = {}
-combos = [(f"tile2048_{i}", 2048, 6) for i in range(7)] + [(f"plain_{i}", _lib.pitch_for(W), 6) for i in range(7)]
-for name, pitch, parts in [(f"{n}_p{p}", t, p) for n, t, p in combos]:
+combos = [(f"{nm}_{mn}", t, md) for nm, t in (("plain", _lib.pitch_for(W)), ("tile1024", 1024), ("tile4096", 4096), ("tile16384", 16384))
+          for mn, md in (("fused", 100), ("splitnt", 0), ("splitcached", 200))]
+for name, pitch, parts in combos:
     pt, ab = ops.adi_buffers(W, D, 3, dev, pitch, parents=True, children=True)
     variants[name] = (pt, ab, parts)
     print(name, hex(ab["children"].data_ptr()), hex(ab["parents"].data_ptr()))
@@ -23,7 +24,7 @@ acts = torch.randint(0, 12, (n,), dtype=torch.uint8, device=dev); done = torch.e
 res = {k: [] for k in list(variants) + ["step4M"]}
 for r in range(6):
     for name, (pt, ab, parts) in variants.items():
-        L.rc_set_variant(parts * 1000)
+        L.rc_set_variant(parts)
         fn = lambda: ops.adi_generate(W, D, 3, pt, dev, seed=2024, **ab)
         if r == 0: run(fn, 3)
         res[name].append(run(fn, 20))

@@ -1,0 +1,35 @@
+"""bench.py prints ONE JSON line with the contract's keys (GPU), and its CPU leg works on its own (CPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpu_baseline_leg_shape():
+    sys.path.insert(0, ROOT)
+    import bench
+    cb = bench.cpu_baseline(budget_s=0.5)
+    assert cb["kind"] == "port" and cb["unit"] == "steps/s" and cb["cores"] >= 1 and cb["value"] > 1e6
+    assert cb["single_core_steps_per_s"] > 1e6 and cb["numpy_env_1core_steps_per_s"] > 1e3 and "sample" in cb
+
+
+@pytest.mark.gpu
+def test_bench_json_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--no-cpu"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["unit"] == "steps/s" and d["dtype"] == "u8" and d["vs_baseline"] is None
+    assert d["scaling"] == "weak" and d["higher_is_better"] is True and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert d["value"] > 1e9                     # the round's floor target: >= 1e9 cube-move steps/s

@@ -429,3 +429,36 @@ def test_full_size_properties(ops, L):
     ops.is_solved(st, n, 3, done)
     assert int(done.sum()) < n // 1000
     assert L.read_status() == 0
+
+
+def test_empty_batches_are_noops(ops, L):
+    st = ops.alloc_states(16, 3, "cuda")
+    st.fill_(3)
+    acts = torch.zeros(16, dtype=torch.uint8, device="cuda")
+    done = torch.full((16,), 9, dtype=torch.uint8, device="cuda")
+    ops.fill_solved(st, 0, 3)
+    ops.apply_moves(st, st, acts, 0, 3, None, done)
+    ops.scramble(st, 0, 3, 5)
+    ops.is_solved(st, 0, 3, done)
+    assert bool((st == 3).all()) and bool((done == 9).all())
+    pt, bufs = ops.adi_buffers(16, 2, 3, "cuda", parents=True)
+    ops.adi_generate(0, 2, 3, pt, "cuda", **bufs)
+    ops.adi_generate(16, 0, 3, pt, "cuda")
+    assert L.read_status() == 0
+
+
+def test_sixteen_million_cubes_identities(ops, L):
+    """Largest batch exercised (2^24 cubes, 906 MB of stickers, 512 tiles): X then X' and the checksum of checksums."""
+    n = 1 << 24
+    st = ops.alloc_states(n, 3, "cuda")
+    ops.fill_solved(st, n, 3)
+    ops.scramble(st, n, 3, 12, seed=99)
+    ref_sum = st.sum(dim=(0, 2), dtype=torch.int64)               # per-row checksums
+    assert int(ref_sum.sum()) == n * sum(9 * c for c in range(6))  # every cube still has 9 stickers of each colour
+    acts = torch.randint(0, 12, (n,), dtype=torch.uint8, device="cuda")
+    tmp = torch.empty_like(st)
+    ops.apply_moves(st, tmp, acts, n, 3)
+    assert int(tmp.sum(dtype=torch.int64)) == int(ref_sum.sum())
+    ops.apply_moves(tmp, tmp, acts ^ 1, n, 3)
+    assert torch.equal(tmp, st)
+    assert L.read_status() == 0

@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(StepArgs a) {
 
 // ----------------------------------------------------------- step + dense one-hot (LDS stage)
 constexpr int kDenseBlock = 256;
-// TILE cubes per workgroup (64 | 256 | 1024): the first TILE/4 lanes compute the pack's codes, then
+// TILE cubes per workgroup (64 | 256): the first TILE/4 lanes compute the pack's codes, then
 // all 256 threads stream the dense rows.  Small tiles keep small batches (MCTS leaves) spread over
 // the chip: 4096 cubes are 64 workgroups at TILE = 64 but only 4 at TILE = 1024.
 // LDS row pitch TILE + 4 bytes: rows fall on different banks for the byte reads of dense_write.
@@ -499,7 +499,13 @@ int dispatch_step(const StepArgs &a, hipStream_t st) {
     }
 }
 
-inline int dense_tile(int64_t n) { return n >= ((int64_t)1 << 19) ? 1024 : n >= ((int64_t)1 << 17) ? 256 : 64; }
+// Measured at 1M cubes (tools/microbench.py densetile): 256-cube tiles 5.4 TB/s (f32) / 6.3 TB/s (u8) against
+// 4.9 / 5.4 with 1024-cube tiles -- shorter private write streams per workgroup (DESIGN.md "ADI write ceiling").
+inline int dense_tile(int64_t n) {
+    const int forced = (g_variant / 100000) % 10;  // rc_set_variant: 100000 / 200000 force 64 / 256
+    if (forced) return forced == 1 ? 64 : 256;
+    return n >= ((int64_t)1 << 17) ? 256 : 64;
+}
 
 template <class T, bool MOVE, bool STORE, int TILE>
 int launch_dense_t(const StepArgs &a, void *onehot, int fmt, hipStream_t st) {
@@ -516,7 +522,6 @@ int launch_dense_t(const StepArgs &a, void *onehot, int fmt, hipStream_t st) {
 template <class T, bool MOVE, bool STORE>
 int launch_dense(const StepArgs &a, void *onehot, int fmt, hipStream_t st) {
     switch (dense_tile(a.n)) {
-        case 1024: return launch_dense_t<T, MOVE, STORE, 1024>(a, onehot, fmt, st);
         case 256: return launch_dense_t<T, MOVE, STORE, 256>(a, onehot, fmt, st);
         default: return launch_dense_t<T, MOVE, STORE, 64>(a, onehot, fmt, st);
     }
@@ -682,7 +687,6 @@ int rc_onehot_from_code(const uint8_t *code, int64_t n, int64_t code_pitch, int 
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
         switch (dense_tile(n)) {
-            case 1024: return launch_code_to_dense<T, 1024>(code, n, code_pitch, sh, onehot, fmt, S(stream));
             case 256: return launch_code_to_dense<T, 256>(code, n, code_pitch, sh, onehot, fmt, S(stream));
             default: return launch_code_to_dense<T, 64>(code, n, code_pitch, sh, onehot, fmt, S(stream));
         }

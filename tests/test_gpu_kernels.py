@@ -179,7 +179,7 @@ def test_apply_moves_dense_onehot(ops, L, oracle, cs, fmt_name, n, pitch):
     assert torch.equal(oh, oh3)
 
 
-@pytest.mark.parametrize("n", [150_000, 600_000])          # dense tile sizes 256 and 1024 (small n uses 64)
+@pytest.mark.parametrize("n", [150_000, 600_000])          # dense tile size 256 (small n uses 64)
 def test_dense_onehot_large_tiles(ops, L, n):
     st = ops.alloc_states(n, 3, "cuda")
     ops.fill_solved(st, n, 3)

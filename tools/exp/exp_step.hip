@@ -43,6 +43,38 @@ __global__ void __launch_bounds__(BLOCK, WPE) k_step(Args a) {
     if constexpr (MOVE) st<V, false>(a.done + n0, done_bytes(unsolved<T, V>(s)));
 }
 
+// The design as literally stated in BASELINE.json's north_star: sticker rows staged in LDS, move applied as a
+// per-cube BYTE GATHER through a constant-memory permutation table (divergent index -> vector loads).
+__constant__ PermTable<Cube3> c_perm{};
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_step_table(Args a) {
+    constexpr int TP = BLOCK * 4 + 4;                      // LDS row pitch (bytes), +4 spreads rows over banks
+    __shared__ __attribute__((aligned(16))) uint8_t tile[T::S * TP];
+    const int64_t g0 = (int64_t)blockIdx.x * (BLOCK * 4);
+    const uint32_t lo = threadIdx.x * 4;
+    const int64_t t = g0 / a.tile; const int64_t base = t * T::S * a.tile + (g0 - t * a.tile);
+    { const uint8_t *row = a.in + base;
+#pragma unroll
+      for (int i = 0; i < T::S; ++i) { *reinterpret_cast<uint32_t *>(tile + i * TP + lo) = *reinterpret_cast<const uint32_t *>(row + lo); row += a.tile; } }
+    const uint32_t act = *reinterpret_cast<const uint32_t *>(a.act + g0 + lo);
+    __syncthreads();
+    uint32_t uns = 0, first[6];
+    uint8_t *row = a.out + base;
+#pragma unroll 6
+    for (int i = 0; i < T::S; ++i) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int src = c_perm.v[(act >> (8 * j)) & 0xff][i];
+            o |= (uint32_t)tile[src * TP + lo + j] << (8 * j);
+        }
+        *reinterpret_cast<uint32_t *>(row + lo) = o; row += a.tile;
+        if (i % 9 == 0) first[i / 9] = o; else uns |= o ^ first[i / 9];
+    }
+    Pk<1> u; u.d[0] = uns;
+    *reinterpret_cast<uint32_t *>(a.done + g0 + lo) = done_bytes(u).d[0];
+}
+
 // persistent, software pipelined: each wave walks items; next item's rows are loaded while the current is computed
 template <int V, bool NT>
 __global__ void __launch_bounds__(64) k_step_pipe(Args a, int64_t items) {
@@ -142,15 +174,17 @@ int main(int argc, char **argv) {
         double t = timeit([&] { a.in = buf[0]; a.out = buf[1]; hipLaunchKernelGGL((k_step<V, true, true, 64, true, INP, WPE>), dim3(blocks), dim3(64), 0, 0, a); std::swap(buf[0], buf[1]); }); \
         report(NAME, t, bytes); }
         for (int rep = 0; rep < 2; ++rep) {
+            { Args a{buf[0], buf[1], act, done, n, pitch, 32768};
+              double t = timeit([&] { a.in = buf[0]; a.out = buf[1]; hipLaunchKernelGGL((k_step_table<256>), dim3(n / 1024), dim3(256), 0, 0, a); std::swap(buf[0], buf[1]); });
+              report("LITERAL: LDS tile + constant-table byte gather b256", t, bytes); }
+            { Args a{buf[0], buf[1], act, done, n, pitch, 32768};
+              double t = timeit([&] { a.in = buf[0]; a.out = buf[1]; hipLaunchKernelGGL((k_step_table<64>), dim3(n / 256), dim3(64), 0, 0, a); std::swap(buf[0], buf[1]); });
+              report("LITERAL: LDS tile + constant-table byte gather b64", t, bytes); }
             RUN(2, false, true, 64, true, 32768, "rowcopy V2 nt tiled32768");
             RUN(4, false, true, 64, true, 32768, "rowcopy V4 nt tiled32768");
             RUN(1, true, true, 64, true, 32768, "step V1 nt tiled32768");
             RUN(2, true, true, 64, true, 32768, "step V2 nt tiled32768");
             RUN(4, true, true, 64, true, 32768, "step V4 nt tiled32768");
-            RUNI(1, true, 6, "step V1 inplace wpe6");
-            RUNI(2, true, 3, "step V2 inplace wpe3");
-            RUNI(2, true, 4, "step V2 inplace wpe4");
-            RUNI(4, true, 2, "step V4 inplace wpe2");
             RUNI(2, false, 3, "step V2 outofplace wpe3");
             RUNI(2, false, 4, "step V2 outofplace wpe4");
             RUNI(4, false, 2, "step V4 outofplace wpe2");

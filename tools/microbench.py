@@ -69,6 +69,22 @@ def main():
             t = timeit(f)
             out.append(dict(k=f"step_code_v{var}", ms=t * 1e3, Gsteps=n / t / 1e9, GBps=130 * n / t / 1e9))
         L.rc_set_variant(0)
+    if "densetile" in which:
+        m = 1 << 20
+        oh = torch.empty((m, 20, 24), dtype=torch.float32, device="cuda")
+        oh8 = torch.empty((m, 20, 24), dtype=torch.uint8, device="cuda")
+        code = ops.alloc_code(m, 3, "cuda")
+        ops.encode(a, m, 3, code, _lib.FMT_CODE)
+        for rep in range(2):
+            for forced, name in ((100000, 64), (200000, 256), (300000, 1024)):
+                L.rc_set_variant(forced)
+                t = timeit(lambda: ops.apply_moves(a, b, acts, m, 3, None, done, oh, _lib.FMT_F32), iters=10)
+                out.append(dict(k=f"step_dense_f32_1M_tile{name}", ms=t * 1e3, GBps=(110 + 1920) * m / t / 1e9))
+                t = timeit(lambda: ops.apply_moves(a, b, acts, m, 3, None, done, oh8, _lib.FMT_U8), iters=10)
+                out.append(dict(k=f"step_dense_u8_1M_tile{name}", ms=t * 1e3, GBps=(110 + 480) * m / t / 1e9))
+                t = timeit(lambda: ops.onehot_from_code(code, m, 3, oh), iters=10)
+                out.append(dict(k=f"code_to_dense_f32_1M_tile{name}", ms=t * 1e3, GBps=(20 + 1920) * m / t / 1e9))
+        L.rc_set_variant(0)
     if "dense" in which:
         m = 1 << 20
         for fmt, name, bpc in ((_lib.FMT_U8, "u8", 480), (_lib.FMT_F16, "f16", 960), (_lib.FMT_F32, "f32", 1920)):

@@ -23,7 +23,7 @@ stats = glob.glob(os.path.join(G, f"{tag}_prof_stats", "**", "*_kernel_stats.csv
 if stats:
     shutil.copy(stats[0], os.path.join(P, f"{rnd}_kernel_stats.csv"))
 pmc = {}
-for name in ("fetch", "write"):
+for name in ("fetch", "write", "sq"):
     for f in glob.glob(os.path.join(G, f"{tag}_prof_{name}", "**", "*_counter_collection.csv"), recursive=True):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):

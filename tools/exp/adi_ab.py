@@ -3,6 +3,8 @@ import os, sys, statistics
 sys.path.insert(0, os.getcwd())
 import torch
 from rubiks_cube_solver_amd import _lib, ops
+if os.environ.get('RC_LIB'): _lib.LIB_PATH = os.environ['RC_LIB']
+print('lib', _lib.LIB_PATH)
 L = _lib.lib()
 W, D, dev = 100_000, 30, torch.device("cuda", 0)
 def run(fn, iters):
@@ -12,8 +14,7 @@ def run(fn, iters):
     s1.record(); torch.cuda.synchronize()
     return s0.elapsed_time(s1) / iters
 variants = {}
-combos = [(f"{nm}_{mn}", t, md) for nm, t in (("plain", _lib.pitch_for(W)), ("tile1024", 1024), ("tile4096", 4096), ("tile16384", 16384))
-          for mn, md in (("fused", 100), ("splitnt", 0), ("splitcached", 200))]
+combos = [(f"{nm}_p{pp}", t, pp * 1000) for nm, t in (("plain", _lib.pitch_for(W)), ("tile4096", 4096)) for pp in (6, 12)]
 for name, pitch, parts in combos:
     pt, ab = ops.adi_buffers(W, D, 3, dev, pitch, parents=True, children=True)
     variants[name] = (pt, ab, parts)

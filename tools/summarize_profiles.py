@@ -22,8 +22,11 @@ os.makedirs(P, exist_ok=True)
 stats = glob.glob(os.path.join(G, f"{tag}_prof_stats", "**", "*_kernel_stats.csv"), recursive=True)
 if stats:
     shutil.copy(stats[0], os.path.join(P, f"{rnd}_kernel_stats.csv"))
+micro = glob.glob(os.path.join(G, f"{tag}_prof_micro", "**", "*_kernel_stats.csv"), recursive=True)
+if micro:
+    shutil.copy(micro[0], os.path.join(P, f"{rnd}_kernel_stats_microbench.csv"))
 pmc = {}
-for name in ("fetch", "write", "sq"):
+for name in ("fetch", "write", "sq", "microwrite"):
     for f in glob.glob(os.path.join(G, f"{tag}_prof_{name}", "**", "*_counter_collection.csv"), recursive=True):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):

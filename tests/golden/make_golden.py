@@ -10,7 +10,8 @@ shims:
 Nothing from the reference is copied: the fixtures hold inputs (action sequences,
 seeds, stub-model weights) and the outputs the reference computed for them.
 
-    python -B tests/golden/make_golden.py
+    python -B tests/golden/make_golden.py            # everything
+    python -B tests/golden/make_golden.py mcts       # only the named groups (tables walks reset adi expand encode mcts)
 
 Fixtures written (all small, np.savez_compressed):
   tables_333.npz   G1  tables as data (perm table, piece defs, hash weights, LUTs)
@@ -22,6 +23,9 @@ Fixtures written (all small, np.savez_compressed):
   expand_333.npz   G6  12-child expansion of random leaves (MCTS.expand's env work)
   encode_333.npz   G7  getOP_3/pos_to_state_3 on arbitrary (unreachable) colourings
                    whose hashes stay inside the LUTs; isSolved_3 on recoloured cubes
+  mcts_333.npz     G8  the reference's MCTS (mcts.py) driven by a deterministic stub model and a
+                   seeded `random`: simulations needed, returned action lists, root statistics;
+                   plus reset(seed, 1000) end states for seeds 0..19 (test.py:166,279 style)
 """
 import hashlib
 import os
@@ -66,6 +70,8 @@ def cols_of(onehot):
 
 
 def main():
+    groups = set(sys.argv[1:])
+    want = lambda g: not groups or g in groups
     torch, cube_env, py333 = import_reference()
     torch.set_num_threads(1)
     dev = torch.device("cpu")
@@ -76,6 +82,10 @@ def main():
     env = cube_env.CubeEnv(dev, cube_size=3)
     assert env.action_to_sim_action[3] == names
     assert [py333.moveInds[n] for n in names] == list(range(12))
+    if want("mcts"):
+        golden_mcts(torch, cube_env, env)
+    if groups and not (groups - {"mcts"}):
+        return
     np.savez_compressed(
         os.path.join(HERE, "tables_333.npz"),
         moveDefs=py333.moveDefs.astype(np.uint8),
@@ -248,6 +258,61 @@ def main():
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+def golden_mcts(torch, cube_env, env):
+    """G8: run the reference's own MCTS class with a deterministic stub model."""
+    import random
+
+    import mcts as ref_mcts
+
+    rng = np.random.default_rng(4321)
+    wv = (rng.standard_normal(480) * 0.05).astype(np.float32)
+    wp = (rng.standard_normal((480, 12)) * 0.3).astype(np.float32)
+
+    class Stub:
+        """predict(state) -> (value[1], softmax policy[12]) as model.py:78-91 returns them."""
+
+        def predict(self, x):
+            f = np.asarray(x, dtype=np.float32).reshape(-1)
+            logits = f @ wp
+            e = np.exp(logits - logits.max())
+            return np.array([f @ wv], np.float32), (e / e.sum()).astype(np.float32)
+
+    cfg = {"mcts": {"virtual_loss_const": 150, "cpuct": 1.0, "value_min": -10.0, "numMCTSSim": 50}, "test": {"cube_size": 3}}
+    cases = [(s, k) for k in (1, 2, 3, 4) for s in range(6)]
+    sims, sol, root_visits, root_values = [], [], [], []
+    for seed, k in cases:
+        state = env.reset(seed=seed, scramble_count=k)
+        random.seed(1000 + 17 * seed + k)
+        tree = ref_mcts.MCTS(Stub(), cfg)
+        found, used = None, 0
+        for i in range(60):
+            used = i + 1
+            found = tree.train(state, env)
+            if found is not None:
+                break
+        sims.append(used)
+        a = np.full(16, 255, np.uint8)
+        if found is not None:
+            a[:len(found)] = found
+        sol.append(a)
+        root = tree.children_and_data[np.array2string(state)]
+        root_visits.append(np.array(root[tree.n_of_v_i], np.int64))
+        root_values.append(np.array([float(np.asarray(v).reshape(-1)[0]) for v in root[tree.s_i]], np.float64))
+    seeds_long = np.arange(20)
+    long_st = np.zeros((20, 54), np.uint8)
+    for i, s in enumerate(seeds_long):
+        env.reset(seed=int(s), scramble_count=1000)
+        long_st[i] = env.sim_cube
+    np.savez_compressed(
+        os.path.join(HERE, "mcts_333.npz"),
+        wv=wv, wp=wp, seeds=np.array([c[0] for c in cases]), ks=np.array([c[1] for c in cases]),
+        random_seed=np.array([1000 + 17 * s + k for s, k in cases]), sims=np.array(sims), solution=np.stack(sol),
+        root_visits=np.stack(root_visits), root_values=np.stack(root_values),
+        long_seeds=seeds_long, long_k=np.int64(1000), long_stickers=long_st,
+    )
+    print("mcts:", list(zip(cases, sims)))
 
 
 if __name__ == "__main__":

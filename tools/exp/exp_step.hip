@@ -173,21 +173,12 @@ int main(int argc, char **argv) {
         const int64_t blocks = n / (64 * 4 * V); \
         double t = timeit([&] { a.in = buf[0]; a.out = buf[1]; hipLaunchKernelGGL((k_step<V, true, true, 64, true, INP, WPE>), dim3(blocks), dim3(64), 0, 0, a); std::swap(buf[0], buf[1]); }); \
         report(NAME, t, bytes); }
-        for (int rep = 0; rep < 2; ++rep) {
-            { Args a{buf[0], buf[1], act, done, n, pitch, 32768};
-              double t = timeit([&] { a.in = buf[0]; a.out = buf[1]; hipLaunchKernelGGL((k_step_table<256>), dim3(n / 1024), dim3(256), 0, 0, a); std::swap(buf[0], buf[1]); });
-              report("LITERAL: LDS tile + constant-table byte gather b256", t, bytes); }
-            { Args a{buf[0], buf[1], act, done, n, pitch, 32768};
-              double t = timeit([&] { a.in = buf[0]; a.out = buf[1]; hipLaunchKernelGGL((k_step_table<64>), dim3(n / 256), dim3(64), 0, 0, a); std::swap(buf[0], buf[1]); });
-              report("LITERAL: LDS tile + constant-table byte gather b64", t, bytes); }
-            RUN(2, false, true, 64, true, 32768, "rowcopy V2 nt tiled32768");
-            RUN(4, false, true, 64, true, 32768, "rowcopy V4 nt tiled32768");
-            RUN(1, true, true, 64, true, 32768, "step V1 nt tiled32768");
-            RUN(2, true, true, 64, true, 32768, "step V2 nt tiled32768");
-            RUN(4, true, true, 64, true, 32768, "step V4 nt tiled32768");
-            RUNI(2, false, 3, "step V2 outofplace wpe3");
-            RUNI(2, false, 4, "step V2 outofplace wpe4");
-            RUNI(4, false, 2, "step V4 outofplace wpe2");
+        for (int rep = 0; rep < 3; ++rep) {
+            RUN(2, true, true, 64, true, 32768, "step V2 nt b64 tiled32768");
+            RUN(2, true, true, 128, true, 32768, "step V2 nt b128 tiled32768");
+            RUN(2, true, true, 256, true, 32768, "step V2 nt b256 tiled32768");
+            RUNI(2, false, 2, "step V2 nt b64 wpe2 tiled32768");
+            RUNI(2, false, 3, "step V2 nt b64 wpe3 tiled32768");
         }
     }
     return 0;

@@ -39,6 +39,26 @@ template <int V, bool NT, bool CHILD_IN_TILE> __global__ void __launch_bounds__(
         }
 }
 
+// depth-sliced ADI shape: each wave lives for DS depths only (blocks ordered depth-slice major)
+template <int V> __global__ void __launch_bounds__(64) k_adi_slice(unsigned char *out, int64_t n_walks, int64_t pitch, int shift, int64_t tiles,
+                                                             int depth, int parts, int ds, int64_t items_per_slice, unsigned v) {
+    typedef unsigned int vec __attribute__((ext_vector_type(V)));
+    const int64_t slice = blockIdx.x / items_per_slice, item = blockIdx.x - slice * items_per_slice;
+    const int64_t g = item / parts; const int part = (int)(item - g * parts);
+    const int64_t g0 = g * (64 * 4 * V); const unsigned lo = threadIdx.x * 4 * V;
+    if (g0 + lo >= n_walks) return;
+    const int64_t toff = g0 + (g0 >> shift) * 53 * pitch;
+    vec x; for (int k = 0; k < V; ++k) x[k] = v + k;
+    const int d1 = (int)min((int64_t)depth, (slice + 1) * ds);
+    for (int d = (int)(slice * ds); d < d1; ++d)
+        for (int c = part; c < 12; c += parts) {
+            unsigned char *row = out + ((int64_t)(d * 12 + c) * tiles) * 54 * pitch + toff;
+            asm volatile("" : "+s"(row));
+#pragma unroll
+            for (int i = 0; i < 54; ++i) { *(vec *)(row + lo) = x; row += pitch; }
+        }
+}
+
 template <class F> double timeit(F &&f, int iters = 10) {
     for (int i = 0; i < 3; i++) f();
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -64,32 +84,18 @@ int main() {
     { double t = timeit([&] { CK(hipMemsetAsync(buf, 1, bytes, 0)); }); printf("hipMemsetAsync: %.1f GB/s\n", bytes / t / 1e9); }
     {
         const int64_t W = 100000; const int D = 30;
-        struct Cfg { int64_t pitch; int V; int parts; };
-        std::vector<Cfg> cfgs;
-        for (int64_t pitch : {256, 512, 1024, 4096})
-            for (int V : {1, 2})
-                for (int parts : {1, 2, 6}) cfgs.push_back({pitch, V, parts});
-        for (auto c : cfgs) {
-            if (c.pitch < 64 * 4 * c.V) continue;
-            const bool tiled = c.pitch < W; const int64_t tiles = tiled ? (W + c.pitch - 1) / c.pitch : 1;
-            int shift = 63; if (tiled) { shift = 0; while (((int64_t)1 << shift) < c.pitch) ++shift; }
-            const int64_t need = (int64_t)D * 12 * tiles * 54 * c.pitch; if (need > bytes) { printf("skip\n"); continue; }
-            const int64_t groups = (W + 64 * 4 * c.V - 1) / (64 * 4 * c.V);
+        for (int64_t pitch : {100096, 4096})
+        for (int V : {1, 2})
+        for (int parts : {1, 3, 12})
+        for (int ds : {1, 2, 5, 30}) {
+            const bool tiled = pitch < W; const int64_t tiles = tiled ? (W + pitch - 1) / pitch : 1;
+            int shift = 63; if (tiled) { shift = 0; while (((int64_t)1 << shift) < pitch) ++shift; }
+            const int64_t groups = (W + 64 * 4 * V - 1) / (64 * 4 * V), per = groups * parts, slices = (D + ds - 1) / ds;
             double t = timeit([&] {
-                if (c.V == 1) hipLaunchKernelGGL((k_adi_shape<1, true, false>), dim3(groups * c.parts), dim3(64), 0, 0, (unsigned char *)buf, W, c.pitch, shift, tiles, D, c.parts, 1u);
-                if (c.V == 2) hipLaunchKernelGGL((k_adi_shape<2, true, false>), dim3(groups * c.parts), dim3(64), 0, 0, (unsigned char *)buf, W, c.pitch, shift, tiles, D, c.parts, 1u);
+                if (V == 1) hipLaunchKernelGGL((k_adi_slice<1>), dim3(per * slices), dim3(64), 0, 0, (unsigned char *)buf, W, pitch, shift, tiles, D, parts, ds, per, 1u);
+                else hipLaunchKernelGGL((k_adi_slice<2>), dim3(per * slices), dim3(64), 0, 0, (unsigned char *)buf, W, pitch, shift, tiles, D, parts, ds, per, 1u);
             }, 5);
-            double t2 = timeit([&] {
-                if (c.V == 1) hipLaunchKernelGGL((k_adi_shape<1, true, true>), dim3(groups * c.parts), dim3(64), 0, 0, (unsigned char *)buf, W, c.pitch, shift, tiles, D, c.parts, 1u);
-                if (c.V == 2) hipLaunchKernelGGL((k_adi_shape<2, true, true>), dim3(groups * c.parts), dim3(64), 0, 0, (unsigned char *)buf, W, c.pitch, shift, tiles, D, c.parts, 1u);
-            }, 5);
-            double t3 = timeit([&] {
-                if (c.V == 1) hipLaunchKernelGGL((k_adi_shape<1, false, true>), dim3(groups * c.parts), dim3(64), 0, 0, (unsigned char *)buf, W, c.pitch, shift, tiles, D, c.parts, 1u);
-                if (c.V == 2) hipLaunchKernelGGL((k_adi_shape<2, false, true>), dim3(groups * c.parts), dim3(64), 0, 0, (unsigned char *)buf, W, c.pitch, shift, tiles, D, c.parts, 1u);
-            }, 5);
-            printf("  child-in-tile: nt %.1f GB/s  cached %.1f GB/s | ", (double)D * 12 * 54 * W / t2 / 1e9, (double)D * 12 * 54 * W / t3 / 1e9);
-            const double by = (double)D * 12 * 54 * W;
-            printf("adi-shape pitch %6lld V%d parts %2d waves %5lld: %7.1f us  %.1f GB/s\n", (long long)c.pitch, c.V, c.parts, (long long)(groups * c.parts), t * 1e6, by / t / 1e9);
+            printf("adi-slice pitch %6lld V%d parts %2d ds %2d waves %6lld: %7.1f us  %.1f GB/s\n", (long long)pitch, V, parts, ds, (long long)(per * slices), t * 1e6, (double)D * 12 * 54 * W / t / 1e9);
             fflush(stdout);
         }
     }

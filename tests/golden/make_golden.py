@@ -23,6 +23,8 @@ Fixtures written (all small, np.savez_compressed):
   expand_333.npz   G6  12-child expansion of random leaves (MCTS.expand's env work)
   encode_333.npz   G7  getOP_3/pos_to_state_3 on arbitrary (unreachable) colourings
                    whose hashes stay inside the LUTs; isSolved_3 on recoloured cubes
+  rollout_333.npz  G9  greedy solve loops of train.py:183-193 / test.py:126-151 with the reference's own
+                   DeepCube (model.py, small hidden dims, seeded init): actions taken and solve step
   mcts_333.npz     G8  the reference's MCTS (mcts.py) driven by a deterministic stub model and a
                    seeded `random`: simulations needed, returned action lists, root statistics;
                    plus reset(seed, 1000) end states for seeds 0..19 (test.py:166,279 style)
@@ -84,7 +86,9 @@ def main():
     assert [py333.moveInds[n] for n in names] == list(range(12))
     if want("mcts"):
         golden_mcts(torch, cube_env, env)
-    if groups and not (groups - {"mcts"}):
+    if want("rollout"):
+        golden_rollout(torch, env)
+    if groups and not (groups - {"mcts", "rollout"}):
         return
     np.savez_compressed(
         os.path.join(HERE, "tables_333.npz"),
@@ -258,6 +262,38 @@ def main():
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+def golden_rollout(torch, env):
+    """G9: the reference's model class + its greedy loops (no mask: train.py:183-193; mask: test.py:126-151)."""
+    import model as ref_model
+
+    torch.manual_seed(7)
+    net = ref_model.DeepCube([20, 24], 12, [64, 32, 16]).eval()
+    T, ks, n_seeds = 12, (1, 2, 3), 30
+    out = {}
+    for mask in (False, True):
+        acts = np.full((len(ks), n_seeds, T), 255, np.uint8)
+        solved_at = np.zeros((len(ks), n_seeds), np.int32)
+        for i, k in enumerate(ks):
+            for j in range(n_seeds):
+                state, pre = env.reset(seed=j * 10, scramble_count=k), None
+                for t in range(1, T + 1):
+                    with torch.no_grad():
+                        x = torch.tensor(state).float().detach()
+                        a = net.get_action(x, pre) if mask else net.get_action(x)
+                    if mask:
+                        pre = a
+                    acts[i, j, t - 1] = a
+                    state, _, done, _ = env.step(a)
+                    if done:
+                        solved_at[i, j] = t
+                        break
+        out["actions_mask" if mask else "actions"] = acts
+        out["solved_at_mask" if mask else "solved_at"] = solved_at
+    sd = {"sd_" + k: v.numpy() for k, v in net.state_dict().items()}
+    np.savez_compressed(os.path.join(HERE, "rollout_333.npz"), ks=np.array(ks), n_seeds=np.int64(n_seeds), T=np.int64(T), **out, **sd)
+    print("rollout: solved", int((out["solved_at"] > 0).sum()), "masked", int((out["solved_at_mask"] > 0).sum()))
 
 
 def golden_mcts(torch, cube_env, env):

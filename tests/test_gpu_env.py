@@ -374,3 +374,31 @@ def test_mcts_matches_reference_golden(mod, golden):
     venv = mod.VecCubeEnv(len(g["long_seeds"]), "cuda", 3, obs=None)       # reset(seed, 1000): test.py:279 style scrambles
     venv.reset(seeds=[int(s) for s in g["long_seeds"]], scramble_count=int(g["long_k"]))
     assert (venv.sim_cube.cpu().numpy() == g["long_stickers"]).all()
+
+
+def test_greedy_rollout_matches_reference_golden(mod, golden):
+    """G9: the reference's DeepCube (weights from the fixture) driving greedy_rollout on the GPU reproduces the
+    reference's per-cube solve loops: every action taken and the step at which each cube was solved."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from bench_cfg5 import DeepCubeStandIn          # same layer layout as model.py:7-45 -> loads the reference state_dict
+    from rubiks_cube_solver_amd.rollout import greedy_rollout
+    g = golden("rollout_333")
+    net = DeepCubeStandIn((20, 24), 12, (64, 32, 16))
+    net.load_state_dict({k[3:]: torch.tensor(g[k]) for k in g.files if k.startswith("sd_")})
+    net = net.cuda().eval()
+    ks, n_seeds, T = [int(k) for k in g["ks"]], int(g["n_seeds"]), int(g["T"])
+    seeds = [j * 10 for j in range(n_seeds)] * len(ks)
+    counts = [k for k in ks for _ in range(n_seeds)]
+    for mask, a_key, s_key in ((False, "actions", "solved_at"), (True, "actions_mask", "solved_at_mask")):
+        env = mod.VecCubeEnv(len(seeds), "cuda", 3, obs="onehot")
+        env.reset(seeds=seeds, scramble_count=counts)
+        res = greedy_rollout(net, env, T, mask=mask, sync_every=T)
+        steps = res["solve_step"].cpu().numpy().reshape(len(ks), n_seeds)
+        assert (steps == g[s_key]).all()
+        acts = res["actions"].cpu().numpy().T.reshape(len(ks), n_seeds, -1)          # [k, seed, t]
+        exp = g[a_key]
+        took = exp != 255
+        assert (acts[..., :exp.shape[-1]][took] == exp[took]).all()
+        assert (acts[..., :exp.shape[-1]][~took] == 12).all()                         # parked with the no-op afterwards
+        assert int((steps > 0).sum()) == 14

@@ -10,8 +10,8 @@ code -- lossless, 24x smaller than the printed one-hot.
                get_most_promising_action_index) over one CubeEnv; statistics follow mcts.py.
   BatchedMCTS  R independent roots searched in lockstep: per simulation ONE replay launch brings all
                R leaves into a device buffer (paths padded with the no-op), ONE expansion launch
-               produces R x A children on a side stream while the value/policy net runs on the R
-               leaves; tree statistics stay on the host.
+               produces R x A children (optionally on a side stream) and the value/policy net runs
+               once on the R leaves; tree statistics stay on the host.
 
 Tree rules restated from mcts.py: PUCT score U + W - L with U = c * P * sqrt(sum N) / (1 + N)
 (:148-169); W is the MAX of backed-up values (:124-125); a traversed edge gains the virtual loss and
@@ -124,7 +124,11 @@ class BatchedMCTS:
     """R roots searched in lockstep on one GPU (config 5: 4096 roots x 12 children per step)."""
 
     def __init__(self, model, root_stickers, n_roots, cube_size=3, cpuct=1.0, virtual_loss=150.0, value_min=-10.0,
-                 device="cuda", overlap=True):
+                 device="cuda", overlap=False, rngs=None):
+        """rngs: optional list of `random.Random` (one per root) for the untried-node draws (mcts.py:69-70); with
+        root r's generator seeded like a stand-alone run, root r's search is that run (default: the global `random`).
+        overlap: run the expansion on a side stream next to the net forward.  Off by default: at 4096 leaves the
+        expansion takes 9 us and the cross-stream dependencies cost more than that (DESIGN.md "Config 5")."""
         self.model, self.cube_size, self.n = model, cube_size, int(n_roots)
         self.c, self.vl, self.vmin = cpuct, virtual_loss, value_min
         self.dev = torch.device(device)
@@ -133,6 +137,8 @@ class BatchedMCTS:
         self.work = torch.empty_like(root_stickers)
         self.trees = [dict() for _ in range(self.n)]
         self.solution = [None] * self.n
+        self.sims_used = [0] * self.n
+        self.rngs = rngs
         self.onehot = torch.empty((self.n, self.R, self.C), dtype=torch.float32, device=self.dev)
         self.code = ops.alloc_code(self.n, cube_size, self.dev, root_stickers.shape[-1])
         self.ex = ops.expand_buffers(self.n, cube_size, self.dev, root_stickers.shape[-1], children=False, codes=True)
@@ -173,11 +179,13 @@ class BatchedMCTS:
         for r in range(n):
             tree, key, acts, trail = self.trees[r], b"root", [], []
             if self.solution[r] is None:
+                self.sims_used[r] += 1
+                rng = self.rngs[r] if self.rngs is not None else random
                 while True:
                     node = tree.get(key)
                     if node is None or not node.children:
                         break
-                    a = random.randint(0, self.A - 1) if sum(node.visits) == 0 else _puct_best(node, self.c)
+                    a = rng.randint(0, self.A - 1) if sum(node.visits) == 0 else _puct_best(node, self.c)
                     node.vloss[a] += self.vl
                     trail.append((node, a))
                     acts.append(a)

@@ -402,3 +402,32 @@ def test_greedy_rollout_matches_reference_golden(mod, golden):
         assert (acts[..., :exp.shape[-1]][took] == exp[took]).all()
         assert (acts[..., :exp.shape[-1]][~took] == 12).all()                         # parked with the no-op afterwards
         assert int((steps > 0).sum()) == 14
+
+
+def test_batched_mcts_reproduces_reference_runs_in_lockstep(mod, golden):
+    """All 24 scrambles of fixture G8 searched TOGETHER by BatchedMCTS (one replay + one expansion launch + one net
+    forward per simulation), each root with its own seeded generator: every root ends like the reference's
+    stand-alone MCTS run (simulations used, action list, root visit counts, root values)."""
+    import random
+
+    from rubiks_cube_solver_amd.mcts_batched import BatchedMCTS
+    g = golden("mcts_333")
+    wv, wp = torch.tensor(g["wv"]).cuda(), torch.tensor(g["wp"]).cuda()
+
+    def model(x):                                            # the fixture's stub as a batched torch callable
+        f = x.reshape(x.shape[0], -1).float()
+        return (f @ wv).unsqueeze(-1), f @ wp
+
+    n = len(g["seeds"])
+    venv = mod.VecCubeEnv(n, "cuda", 3, obs=None)
+    venv.reset(seeds=[int(s) for s in g["seeds"]], scramble_count=[int(k) for k in g["ks"]])
+    bm = BatchedMCTS(model, venv.stickers, n, 3, rngs=[random.Random(int(s)) for s in g["random_seed"]])
+    for _ in range(60):
+        bm.simulate()
+    for r in range(n):
+        assert bm.sims_used[r] == int(g["sims"][r]), r
+        exp = [int(a) for a in g["solution"][r] if a != 255]
+        assert (bm.solution[r] or []) == exp
+        root = bm.trees[r][b"root"]
+        assert root.visits == g["root_visits"][r].tolist(), r
+        assert np.allclose(root.value, g["root_values"][r], rtol=0, atol=1e-5)

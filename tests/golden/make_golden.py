@@ -25,6 +25,7 @@ Fixtures written (all small, np.savez_compressed):
                    whose hashes stay inside the LUTs; isSolved_3 on recoloured cubes
   rollout_333.npz  G9  greedy solve loops of train.py:183-193 / test.py:126-151 with the reference's own
                    DeepCube (model.py, small hidden dims, seeded init): actions taken and solve step
+  adi_deepcube_333.npz G10 get_random_samples with the reference's DeepCube as the model
   mcts_333.npz     G8  the reference's MCTS (mcts.py) driven by a deterministic stub model and a
                    seeded `random`: simulations needed, returned action lists, root statistics;
                    plus reset(seed, 1000) end states for seeds 0..19 (test.py:166,279 style)
@@ -88,7 +89,9 @@ def main():
         golden_mcts(torch, cube_env, env)
     if want("rollout"):
         golden_rollout(torch, env)
-    if groups and not (groups - {"mcts", "rollout"}):
+    if want("adi_deepcube"):
+        golden_adi_deepcube(torch, env)
+    if groups and not (groups - {"mcts", "rollout", "adi_deepcube"}):
         return
     np.savez_compressed(
         os.path.join(HERE, "tables_333.npz"),
@@ -294,6 +297,27 @@ def golden_rollout(torch, env):
     sd = {"sd_" + k: v.numpy() for k, v in net.state_dict().items()}
     np.savez_compressed(os.path.join(HERE, "rollout_333.npz"), ks=np.array(ks), n_seeds=np.int64(n_seeds), T=np.int64(T), **out, **sd)
     print("rollout: solved", int((out["solved_at"] > 0).sum()), "masked", int((out["solved_at_mask"] > 0).sum()))
+
+
+def golden_adi_deepcube(torch, env):
+    """G10: get_random_samples (cube_env.py:177-252) with the reference's own DeepCube as the model."""
+    import model as ref_model
+
+    torch.manual_seed(11)
+    net = ref_model.DeepCube([20, 24], 12, [64, 32, 16]).eval()
+    n_cubes, depth, temperature, seed = 16, 12, 0.7, 555
+    buf = []
+    np.random.seed(seed)
+    env.get_random_samples(buf, net, depth, n_cubes, temperature)
+    shape = (n_cubes, depth)
+    sd = {"sd_" + k: v.numpy() for k, v in net.state_dict().items()}
+    np.savez_compressed(
+        os.path.join(HERE, "adi_deepcube_333.npz"), seed=np.int64(seed), temperature=np.float64(temperature),
+        cols=np.stack([cols_of(b["state"]) for b in buf]).reshape(*shape, 20),
+        target_value=np.array([b["target_value"] for b in buf], np.float64).reshape(shape),
+        target_policy=np.array([b["target_policy"] for b in buf], np.int64).reshape(shape),
+        error=np.array([b["error"] for b in buf], np.float64).reshape(shape), **sd)
+    print("adi_deepcube:", len(buf), "samples")
 
 
 def golden_mcts(torch, cube_env, env):

@@ -431,3 +431,30 @@ def test_batched_mcts_reproduces_reference_runs_in_lockstep(mod, golden):
         root = bm.trees[r][b"root"]
         assert root.visits == g["root_visits"][r].tolist(), r
         assert np.allclose(root.value, g["root_values"][r], rtol=0, atol=1e-5)
+
+
+def test_get_random_samples_with_reference_deepcube(mod, golden):
+    """G10: same global numpy seed, the reference's DeepCube weights -> the reference's replay-buffer records
+    (values to 1e-5: the net runs batched on 13 x walks states per depth instead of 12 + 1 per sample)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from bench_cfg5 import DeepCubeStandIn
+    g = golden("adi_deepcube_333")
+    net = DeepCubeStandIn((20, 24), 12, (64, 32, 16))
+    net.load_state_dict({k[3:]: torch.tensor(g[k]) for k in g.files if k.startswith("sd_")})
+    net.eval()
+    n, depth = g["target_value"].shape
+    for device in ("cpu", "cuda"):                           # model on the host (the reference's config) and on the GPU
+        env = mod.make_env(torch.device(device), 3)
+        buf = []
+        np.random.seed(int(g["seed"]))
+        env.get_random_samples(buf, net.to(device), depth, n, float(g["temperature"]))
+        assert len(buf) == n * depth
+        same_policy = 0
+        for i, smp in enumerate(buf):
+            c, d = divmod(i, depth)
+            assert (np.argmax(smp["state"], 1) == g["cols"][c, d]).all()
+            assert smp["target_value"] == pytest.approx(g["target_value"][c, d], abs=1e-5)
+            assert smp["error"] == pytest.approx(g["error"][c, d], abs=1e-5)
+            same_policy += smp["target_policy"] == g["target_policy"][c, d]
+        assert same_policy >= len(buf) - 1

@@ -38,7 +38,7 @@
  *                 (getOP_3, assets/py333.py:224-227).  3x3x3: one-hot column of row `slot`
  *                 (pos_to_state_3, py333.py:235-246).  2x2x2: row = code/3,
  *                 column = slot*3 + code%3 (cube_env.py:142-147).
- *   RC_FMT_U8 / RC_FMT_F16 / RC_FMT_F32
+ *   RC_FMT_U8 / RC_FMT_F16 / RC_FMT_BF16 / RC_FMT_F32
  *                 dense [n][R][C] (R,C = 20,24 | 7,21), contiguous per cube, values {0,1}:
  *                 exactly what model.py:31-45 consumes after `.float()`.
  */
@@ -61,6 +61,7 @@ extern "C" {
 #define RC_FMT_U8 2
 #define RC_FMT_F16 3
 #define RC_FMT_F32 4
+#define RC_FMT_BF16 5
 
 #define RC_STATUS_BAD_ACTION 1u
 
@@ -115,7 +116,7 @@ int rc_is_solved(const uint8_t *st, int64_t n_cubes, int64_t pitch, int cube_siz
 int rc_encode(const uint8_t *st, int64_t n_cubes, int64_t pitch, int cube_size, void *onehot,
               int fmt, int64_t code_pitch, void *stream);
 
-/* Dense one-hot [n][R][C] from a compact code buffer (RC_FMT_CODE layout). fmt = U8/F16/F32. */
+/* Dense one-hot [n][R][C] from a compact code buffer (RC_FMT_CODE layout). fmt = U8/F16/BF16/F32. */
 int rc_onehot_from_code(const uint8_t *code, int64_t n_cubes, int64_t code_pitch, int cube_size,
                         void *onehot, int fmt, void *stream);
 

@@ -278,10 +278,12 @@ __device__ __forceinline__ void encode_child(const Pk<V> (&child)[T::S], const P
 
 // ------------------------------------------------------- dense one-hot from an LDS code tile
 // lds_code: [SLOTS][tp] bytes (tp = padded tile width), `ncubes` valid cubes, output element
-// type E in {uint8_t, uint16_t (IEEE half bits), float}; out points at the tile's first cube.
+// type E in {uint8_t, uint16_t (IEEE half bits), Bf16, float}; out points at the tile's first cube.
 template <class E> struct One;
 template <> struct One<uint8_t> { static constexpr uint32_t v = 1u; };
 template <> struct One<uint16_t> { static constexpr uint32_t v = 0x3C00u; };
+struct Bf16 { uint16_t bits; };   // bfloat16 payload (RC_FMT_BF16)
+template <> struct One<Bf16> { static constexpr uint32_t v = 0x3F80u; };
 template <> struct One<float> { static constexpr uint32_t v = 0x3F800000u; };
 
 template <int BYTES> struct UIntOf;

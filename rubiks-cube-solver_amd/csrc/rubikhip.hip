@@ -518,6 +518,7 @@ int launch_dense_t(const StepArgs &a, void *onehot, int fmt, hipStream_t st) {
     const dim3 g((unsigned)blocks), b(kDenseBlock);
     if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_step_dense<T, uint8_t, MOVE, STORE, TILE>), g, b, 0, st, a, static_cast<uint8_t *>(onehot));
     else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_step_dense<T, uint16_t, MOVE, STORE, TILE>), g, b, 0, st, a, static_cast<uint16_t *>(onehot));
+    else if (fmt == RC_FMT_BF16) hipLaunchKernelGGL((k_step_dense<T, Bf16, MOVE, STORE, TILE>), g, b, 0, st, a, static_cast<Bf16 *>(onehot));
     else hipLaunchKernelGGL((k_step_dense<T, float, MOVE, STORE, TILE>), g, b, 0, st, a, static_cast<float *>(onehot));
     RC_HIP(hipGetLastError());
     return RC_OK;
@@ -536,13 +537,14 @@ int launch_code_to_dense(const uint8_t *code, int64_t n, int64_t code_pitch, int
     const dim3 g((unsigned)((n + TILE - 1) / TILE)), b(kDenseBlock);
     if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_code_to_dense<T, uint8_t, TILE>), g, b, 0, st, code, n, code_pitch, sh, static_cast<uint8_t *>(onehot));
     else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_code_to_dense<T, uint16_t, TILE>), g, b, 0, st, code, n, code_pitch, sh, static_cast<uint16_t *>(onehot));
+    else if (fmt == RC_FMT_BF16) hipLaunchKernelGGL((k_code_to_dense<T, Bf16, TILE>), g, b, 0, st, code, n, code_pitch, sh, static_cast<Bf16 *>(onehot));
     else hipLaunchKernelGGL((k_code_to_dense<T, float, TILE>), g, b, 0, st, code, n, code_pitch, sh, static_cast<float *>(onehot));
     RC_HIP(hipGetLastError());
     return RC_OK;
 }
 
 int check_fmt(void *onehot, int fmt, int64_t code_pitch, int64_t n, int *sh_code) {
-    if (fmt < RC_FMT_NONE || fmt > RC_FMT_F32) return fail(RC_EINVAL, "unknown one-hot format%s");
+    if (fmt < RC_FMT_NONE || fmt > RC_FMT_BF16) return fail(RC_EINVAL, "unknown one-hot format%s");
     if ((fmt == RC_FMT_NONE) != (onehot == nullptr)) return fail(RC_EINVAL, "onehot pointer and fmt disagree%s");
     if (onehot && !aligned16(onehot)) return fail(RC_EINVAL, "onehot must be 16-byte aligned%s");
     *sh_code = 63;
@@ -686,7 +688,7 @@ int rc_encode(const uint8_t *stp, int64_t n, int64_t pitch, int cube_size, void 
 int rc_onehot_from_code(const uint8_t *code, int64_t n, int64_t code_pitch, int cube_size, void *onehot, int fmt, void *stream) {
     const int sh = tile_shift(code_pitch, n);
     if (!code || !aligned16(code) || n < 0 || sh < 0) return fail(RC_EINVAL, "bad code buffer / pitch%s");
-    if (fmt < RC_FMT_U8 || fmt > RC_FMT_F32 || !onehot || !aligned16(onehot)) return fail(RC_EINVAL, "rc_onehot_from_code: dense fmt and aligned buffer required%s");
+    if (fmt < RC_FMT_U8 || fmt > RC_FMT_BF16 || !onehot || !aligned16(onehot)) return fail(RC_EINVAL, "rc_onehot_from_code: dense fmt and aligned buffer required%s");
     if (n == 0) return RC_OK;
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);

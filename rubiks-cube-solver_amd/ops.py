@@ -15,7 +15,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from ._lib import FMT_CODE, FMT_F16, FMT_F32, FMT_NONE, FMT_U8, RubikHipError, check, lib, ptr, stream_ptr
+from ._lib import FMT_BF16, FMT_CODE, FMT_F16, FMT_F32, FMT_NONE, FMT_U8, RubikHipError, check, lib, ptr, stream_ptr
 from .tables import ACTION_DIM, STATE_DIM
 
 N_STICKERS = {2: 24, 3: 54}

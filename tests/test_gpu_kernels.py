@@ -146,7 +146,7 @@ def test_apply_moves_vs_oracle(ops, L, oracle, cs, variant, n, pitch):
 
 
 @pytest.mark.parametrize("cs", CS)
-@pytest.mark.parametrize("fmt_name", ["U8", "F16", "F32"])
+@pytest.mark.parametrize("fmt_name", ["U8", "F16", "BF16", "F32"])
 @pytest.mark.parametrize("n,pitch", [(1, None), (6, None), (1023, None), (1024, None), (1025, None), (5000, None), (5000, 1024)])
 def test_apply_moves_dense_onehot(ops, L, oracle, cs, fmt_name, n, pitch):
     fmt = getattr(L, "FMT_" + fmt_name)
@@ -164,8 +164,8 @@ def test_apply_moves_dense_onehot(ops, L, oracle, cs, fmt_name, n, pitch):
     exp_oh = dense_from_code(cs, exp_code)
     _, oracle_oh = oracle.encode(cs, exp_st)
     assert (exp_oh == oracle_oh).all()
-    got = oh.cpu().numpy()
-    assert (got == exp_oh.astype(got.dtype)).all()
+    got = oh.float().cpu().numpy()                      # (numpy has no bfloat16; 0 and 1 are exact in every format)
+    assert (got == exp_oh.astype(np.float32)).all()
     assert (done.cpu().numpy() == exp_done).all() and (rew.cpu().numpy() == exp_rew).all()
     # standalone encode and code -> dense agree
     oh2 = torch.full_like(oh, 5)

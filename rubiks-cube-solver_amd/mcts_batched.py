@@ -124,11 +124,12 @@ class BatchedMCTS:
     """R roots searched in lockstep on one GPU (config 5: 4096 roots x 12 children per step)."""
 
     def __init__(self, model, root_stickers, n_roots, cube_size=3, cpuct=1.0, virtual_loss=150.0, value_min=-10.0,
-                 device="cuda", overlap=False, rngs=None):
+                 device="cuda", overlap=False, rngs=None, graph=False):
         """rngs: optional list of `random.Random` (one per root) for the untried-node draws (mcts.py:69-70); with
         root r's generator seeded like a stand-alone run, root r's search is that run (default: the global `random`).
         overlap: run the expansion on a side stream next to the net forward.  Off by default: at 4096 leaves the
-        expansion takes 9 us and the cross-stream dependencies cost more than that (DESIGN.md "Config 5")."""
+        expansion takes 9 us and the cross-stream dependencies cost more than that (DESIGN.md "Config 5").
+        graph: capture the per-simulation kernel sequence as a hipGraph and replay it (launch-bound loop)."""
         self.model, self.cube_size, self.n = model, cube_size, int(n_roots)
         self.c, self.vl, self.vmin = cpuct, virtual_loss, value_min
         self.dev = torch.device(device)
@@ -143,17 +144,15 @@ class BatchedMCTS:
         self.code = ops.alloc_code(self.n, cube_size, self.dev, root_stickers.shape[-1])
         self.ex = ops.expand_buffers(self.n, cube_size, self.dev, root_stickers.shape[-1], children=False, codes=True)
         self.side = torch.cuda.Stream(self.dev) if overlap else None
+        self.graph, self._graphs, self._paths, self._host = bool(graph), {}, None, None
 
-    @torch.no_grad()
-    def leaves_step(self, paths):
-        """Device part of one simulation: replay `paths` (uint8 [R, depth], no-op padded) from the roots, then
-        expansion (side stream) || leaf one-hot + net forward (main stream).  Returns host arrays."""
+    def _device_step(self, depth):
+        """Kernels of one simulation, all on the current stream (capturable): roots -> work, replay `depth`
+        moves from self._paths, expansion, leaf code + one-hot, net forward."""
         n, cs = self.n, self.cube_size
         self.work.copy_(self.roots)
-        if paths.shape[1]:
-            buf = torch.full((paths.shape[1], _lib.pitch_for(n)), self.A, dtype=torch.uint8)
-            buf[:, :n] = torch.from_numpy(np.ascontiguousarray(paths.T))
-            ops.scramble(self.work, n, cs, paths.shape[1], actions_in=buf.to(self.dev))
+        if depth:
+            ops.scramble(self.work, n, cs, depth, actions_in=self._paths[:depth])
         pitch = self.work.shape[-1]
         if self.side is not None:
             self.side.wait_stream(torch.cuda.current_stream(self.dev))
@@ -167,10 +166,52 @@ class BatchedMCTS:
         policy = torch.softmax(logits, dim=-1)          # model.py:89
         if self.side is not None:
             torch.cuda.current_stream(self.dev).wait_stream(self.side)
-        leaf_code = ops.to_aos(self.code, n).cpu().numpy()
-        child_code = torch.stack([ops.to_aos(self.ex["child_code"][a], n) for a in range(self.A)], 1).cpu().numpy()
-        solved = self.ex["child_solved"][:, :n].t().cpu().numpy().astype(bool)
-        return leaf_code, child_code, solved, value.reshape(-1).cpu().numpy(), policy.cpu().numpy()
+        return value, policy
+
+    @torch.no_grad()
+    def leaves_step(self, paths):
+        """Device part of one simulation for `paths` (uint8 [R, depth], no-op padded).  With graph=True the
+        kernel sequence is captured once per depth bucket as a hipGraph (paths padded with the no-op up to the
+        bucket) and replayed: one launch instead of ~15 (DESIGN.md "Config 5").  Returns host arrays."""
+        n = self.n
+        depth = paths.shape[1]
+        if self._paths is None or self._paths.shape[0] < depth:
+            cap = max(16, 1 << max(depth - 1, 0).bit_length())
+            self._paths = torch.full((cap, _lib.pitch_for(n)), self.A, dtype=torch.uint8, device=self.dev)
+            self._graphs = {}
+        self._paths.fill_(self.A)
+        if depth:
+            self._paths[:depth, :n] = torch.from_numpy(np.ascontiguousarray(paths.T)).to(self.dev)
+        if self.graph:
+            bucket = 0 if depth == 0 else max(4, 1 << (depth - 1).bit_length())      # replay length: no-op padded
+            bucket = min(bucket, self._paths.shape[0])
+            if bucket not in self._graphs:
+                s = torch.cuda.Stream(self.dev)
+                s.wait_stream(torch.cuda.current_stream(self.dev))
+                with torch.cuda.stream(s):
+                    self._device_step(bucket)                                             # warm-up outside capture
+                torch.cuda.current_stream(self.dev).wait_stream(s)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = self._device_step(bucket)
+                self._graphs[bucket] = (g, out)
+            g, (value, policy) = self._graphs[bucket]
+            g.replay()
+        else:
+            value, policy = self._device_step(depth)
+        # one batch of raw downloads into pinned memory, one sync; the [tile][slot][column] -> [root][slot]
+        # reshuffle of ~1 MB happens on the host
+        if self._host is None:
+            pin = lambda t: torch.empty(t.shape, dtype=t.dtype).pin_memory()
+            self._host = [pin(self.code), pin(self.ex["child_code"]), pin(self.ex["child_solved"]), pin(value), pin(policy)]
+        for h, d in zip(self._host, (self.code, self.ex["child_code"], self.ex["child_solved"], value, policy)):
+            h.copy_(d, non_blocking=True)
+        torch.cuda.current_stream(self.dev).synchronize()
+        code_h, cc_h, cs_h, v_h, p_h = (h.numpy() for h in self._host)
+        leaf_code = code_h.transpose(0, 2, 1).reshape(-1, code_h.shape[1])[:n]                      # [n, SLOTS]
+        child_code = cc_h.transpose(1, 3, 0, 2).reshape(-1, self.A, cc_h.shape[2])[:n]             # [n, A, SLOTS]
+        solved = cs_h[:, :n].T.astype(bool)
+        return leaf_code, child_code, solved, v_h.reshape(-1).copy(), p_h.copy()
 
     def simulate(self):
         """One simulation for every unsolved root.  Returns the number of roots solved so far."""

@@ -404,7 +404,8 @@ def test_greedy_rollout_matches_reference_golden(mod, golden):
         assert int((steps > 0).sum()) == 14
 
 
-def test_batched_mcts_reproduces_reference_runs_in_lockstep(mod, golden):
+@pytest.mark.parametrize("graph", [False, True])
+def test_batched_mcts_reproduces_reference_runs_in_lockstep(mod, golden, graph):
     """All 24 scrambles of fixture G8 searched TOGETHER by BatchedMCTS (one replay + one expansion launch + one net
     forward per simulation), each root with its own seeded generator: every root ends like the reference's
     stand-alone MCTS run (simulations used, action list, root visit counts, root values)."""
@@ -421,7 +422,7 @@ def test_batched_mcts_reproduces_reference_runs_in_lockstep(mod, golden):
     n = len(g["seeds"])
     venv = mod.VecCubeEnv(n, "cuda", 3, obs=None)
     venv.reset(seeds=[int(s) for s in g["seeds"]], scramble_count=[int(k) for k in g["ks"]])
-    bm = BatchedMCTS(model, venv.stickers, n, 3, rngs=[random.Random(int(s)) for s in g["random_seed"]])
+    bm = BatchedMCTS(model, venv.stickers, n, 3, rngs=[random.Random(int(s)) for s in g["random_seed"]], graph=graph)
     for _ in range(60):
         bm.simulate()
     for r in range(n):

@@ -110,6 +110,25 @@ def main():
     except Exception as e:
         res["hipgraph_overlapped_step_us"] = None
         res["hipgraph_overlap_error"] = str(e)[:200]
+    # the product's lockstep search: device part of one simulation (replay 8 moves + expand + one-hot + forward)
+    import numpy as np
+    from rubiks_cube_solver_amd.mcts_batched import BatchedMCTS
+    paths = np.random.default_rng(0).integers(0, 12, (n, 8), dtype=np.uint8)
+    for name, kw in (("eager", {}), ("hipgraph", {"graph": True})):
+        bm = BatchedMCTS(model, leaves, n, cs, **kw)
+        bm.leaves_step(paths)
+        bm.leaves_step(paths)
+        torch.cuda.synchronize()
+        if kw:
+            gobj = bm._graphs[8][0]
+            res[f"batched_mcts_device_step_{name}_us"] = timeit(gobj.replay)
+        else:
+            res[f"batched_mcts_device_step_{name}_us"] = timeit(lambda: bm._device_step(8))
+        import time
+        t0 = time.perf_counter()
+        for _ in range(20):
+            bm.leaves_step(paths)
+        res[f"batched_mcts_leaves_step_with_d2h_{name}_us"] = (time.perf_counter() - t0) / 20 * 1e6
     hidden = res["serial_step_us"] - res["overlapped_step_us"]
     res["overlap_hidden_us"] = hidden
     res["overlap_fraction_of_expand"] = hidden / res["expand_stickers_codes_flags_us"]

@@ -14,36 +14,63 @@ from .vec_env import VecCubeEnv
 
 
 @torch.no_grad()
-def greedy_rollout(model, env: VecCubeEnv, max_timesteps, mask=False, sync_every=8):
+def greedy_rollout(model, env: VecCubeEnv, max_timesteps, mask=False, sync_every=8, graph=False):
     """Roll every cube of `env` (obs must be 'onehot') forward greedily from its current state.
+
+    graph=True captures ONE time step (net forward, action choice, rc_apply_moves, bookkeeping) as a hipGraph and
+    replays it: small batches are launch-bound (~15 launches per step otherwise).
 
     Returns dict(solved bool [N], solve_step int32 [N] (0 = not solved within max_timesteps, else the 1-based
     step at which done came, as test.py:151), actions uint8 [T, N] (no-op = action_dim after a cube is done))."""
     if env.obs != "onehot":
         raise ValueError("greedy_rollout needs VecCubeEnv(obs='onehot')")
     n, dev, A = env.num_envs, env.device, env.action_dim
-    obs = env._observe()
+    env._observe()
     active = torch.ones(n, dtype=torch.bool, device=dev)          # the reference starts every trial with done = False
     solve_step = torch.zeros(n, dtype=torch.int32, device=dev)
     pre = torch.full((n,), -1, dtype=torch.int64, device=dev)
-    taken = []
-    for t in range(1, max_timesteps + 1):
-        logits = model(obs.float())[1]
+    taken = torch.full((max_timesteps, n), A, dtype=torch.uint8, device=dev)
+    t_dev = torch.zeros(1, dtype=torch.int64, device=dev)         # 0-based index of the step being taken
+    noop = torch.full((n,), A, dtype=torch.int64, device=dev)
+
+    def one_step():
+        logits = model(env._obs_buf.float())[1]
         top2 = torch.topk(logits, 2, dim=-1).indices               # model.py:71-74: best, else second best
         a = top2[:, 0]
         if mask:
             invalid = torch.where(pre >= 0, pre ^ 1, pre)          # model.py:64-69: U<->U', F<->F', ...
             a = torch.where(a == invalid, top2[:, 1], a)
-            pre = torch.where(active, a, pre)
-        a8 = torch.where(active, a, torch.full_like(a, A)).to(torch.uint8)
-        obs, _, done, _ = env.step(a8)
-        taken.append(a8)
+            pre.copy_(torch.where(active, a, pre))
+        a8 = torch.where(active, a, noop).to(torch.uint8)
+        _, _, done, _ = env.step(a8)
+        taken.scatter_(0, t_dev.expand(1, n), a8.unsqueeze(0))
         newly = active & (done != 0)
-        solve_step = torch.where(newly, torch.full_like(solve_step, t), solve_step)
-        active = active & ~newly
+        solve_step.copy_(torch.where(newly, (t_dev + 1).to(torch.int32).expand(n), solve_step))
+        active.logical_and_(~newly)
+        t_dev.add_(1)
+
+    g = None
+    if graph and max_timesteps > 1:
+        snap = [x.clone() for x in (env.stickers, env._obs_buf, active, solve_step, pre, taken, t_dev)]
+        s = torch.cuda.Stream(dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            one_step()                                             # warm-up outside capture ...
+        torch.cuda.current_stream(dev).wait_stream(s)
+        for x, y in zip((env.stickers, env._obs_buf, active, solve_step, pre, taken, t_dev), snap):
+            x.copy_(y)                                             # ... then rewind to the start state
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            one_step()
+        for x, y in zip((env.stickers, env._obs_buf, active, solve_step, pre, taken, t_dev), snap):
+            x.copy_(y)                                             # capture does not execute, but keep it exact
+    steps_done = 0
+    for t in range(1, max_timesteps + 1):
+        g.replay() if g is not None else one_step()
+        steps_done = t
         if t % sync_every == 0 and not bool(active.any()):
             break
-    return {"solved": solve_step > 0, "solve_step": solve_step, "actions": torch.stack(taken) if taken else None}
+    return {"solved": solve_step > 0, "solve_step": solve_step, "actions": taken[:steps_done]}
 
 
 @torch.no_grad()

@@ -376,7 +376,8 @@ def test_mcts_matches_reference_golden(mod, golden):
     assert (venv.sim_cube.cpu().numpy() == g["long_stickers"]).all()
 
 
-def test_greedy_rollout_matches_reference_golden(mod, golden):
+@pytest.mark.parametrize("graph", [False, True])
+def test_greedy_rollout_matches_reference_golden(mod, golden, graph):
     """G9: the reference's DeepCube (weights from the fixture) driving greedy_rollout on the GPU reproduces the
     reference's per-cube solve loops: every action taken and the step at which each cube was solved."""
     import sys, os
@@ -393,7 +394,7 @@ def test_greedy_rollout_matches_reference_golden(mod, golden):
     for mask, a_key, s_key in ((False, "actions", "solved_at"), (True, "actions_mask", "solved_at_mask")):
         env = mod.VecCubeEnv(len(seeds), "cuda", 3, obs="onehot")
         env.reset(seeds=seeds, scramble_count=counts)
-        res = greedy_rollout(net, env, T, mask=mask, sync_every=T)
+        res = greedy_rollout(net, env, T, mask=mask, sync_every=T, graph=graph)
         steps = res["solve_step"].cpu().numpy().reshape(len(ks), n_seeds)
         assert (steps == g[s_key]).all()
         acts = res["actions"].cpu().numpy().T.reshape(len(ks), n_seeds, -1)          # [k, seed, t]

@@ -41,7 +41,7 @@ def adi_samples(model, cube_size, n_walks, depth, temperature, device="cuda", mo
     mdev = torch.device(model_device) if model_device is not None else _module_device(model, dev)
     per_walk = (A + 1) * R * C * 4
     chunk = max(1, min(n_walks, dense_budget_bytes // per_walk))
-    chunk = min(n_walks, max(256, chunk // 256 * 256)) if n_walks > 256 else n_walks
+    chunk = min(n_walks, max(1024, chunk // 1024 * 1024)) if n_walks > 1024 else n_walks
     weights = [float(d) ** (-1 * temperature) for d in range(1, depth + 1)]  # cube_env.py:247, Python pow
     outs = {k: [] for k in ("state_code", "target_value", "target_policy", "error", "actions")}
     if want_state_dense:
@@ -49,8 +49,12 @@ def adi_samples(model, cube_size, n_walks, depth, temperature, device="cuda", mo
     acts_all = None if actions is None else torch.as_tensor(actions, dtype=torch.uint8)
     for w0 in range(0, n_walks, chunk):
         wc = min(chunk, n_walks - w0)
-        pitch, bufs = ops.adi_buffers(wc, depth, cube_size, dev, parent_code=True, child_code=True)
+        # power-of-two pitch: the A children (and the `depth` parents) of a chunk are then ONE tiled code buffer
+        # of A * tiles (depth * tiles) tiles, so a single launch turns all of them into dense one-hots
+        pitch, bufs = ops.adi_buffers(wc, depth, cube_size, dev, pitch=1024 if wc <= 1024 else ops.ADI_TILE,
+                                      parent_code=True, child_code=True)
         p = bufs["actions_out"].shape[1]                      # padded walk count (tiles * pitch)
+        tiles = p // pitch
         a_in = None
         if acts_all is not None:
             a_host = torch.zeros((depth, p), dtype=torch.uint8)
@@ -58,30 +62,27 @@ def adi_samples(model, cube_size, n_walks, depth, temperature, device="cuda", mo
             a_in = a_host.to(dev)
         ops.adi_generate(wc, depth, cube_size, pitch, dev, seed=seed, stream_id=stream_id, walk_offset=walk_offset + w0,
                          actions_in=a_in, **bufs)
-        dense = torch.empty(((A + 1) * wc, R, C), dtype=torch.float32, device=dev)
-        child_value = torch.zeros((A, p), dtype=torch.float32, device=dev)
+        dense = torch.empty(((A + 1) * p, R, C), dtype=torch.float32, device=dev)      # A child blocks + the parents
         tv = torch.empty((depth, wc), dtype=torch.float32, device=dev)
         tp = torch.empty((depth, wc), dtype=torch.int32, device=dev)
         err = torch.empty((depth, wc), dtype=torch.float64, device=dev)
         for d in range(depth):
-            for a in range(A):
-                ops.onehot_from_code(bufs["child_code"][d, a], wc, cube_size, dense[a * wc:(a + 1) * wc])
-            ops.onehot_from_code(bufs["parent_code"][d], wc, cube_size, dense[A * wc:])
-            v = model(dense.to(mdev))[0].reshape(-1).to(device=dev, dtype=torch.float32)
-            child_value[:, :wc] = v[:A * wc].view(A, wc)
-            pv = v[A * wc:].contiguous()
+            ops.onehot_from_code(bufs["child_code"][d].view(A * tiles, SL, pitch), A * p, cube_size, dense[:A * p])
+            ops.onehot_from_code(bufs["parent_code"][d], wc, cube_size, dense[A * p:A * p + wc])
+            v = model(dense[:A * p + wc].to(mdev))[0].reshape(-1).to(device=dev, dtype=torch.float32)
+            child_value = v[:A * p].view(A, p)                   # exactly rc_adi_targets' [A][pitch] layout
+            pv = v[A * p:].contiguous()
             w = torch.full((wc,), weights[d], dtype=torch.float64, device=dev)
-            tv[d], tp[d], err[d] = ops.adi_targets(child_value, bufs["child_solved"][d], wc, cube_size, pv, w)
+            tv[d], tp[d], err[d] = ops.adi_targets(child_value.contiguous(), bufs["child_solved"][d], wc, cube_size, pv, w)
         outs["state_code"].append(torch.stack([ops.to_aos(bufs["parent_code"][d], wc) for d in range(depth)], 1).contiguous())
         outs["actions"].append(bufs["actions_out"][:, :wc].t().contiguous())
         outs["target_value"].append(tv.t().contiguous())
         outs["target_policy"].append(tp.t().contiguous())
         outs["error"].append(err.t().contiguous())
         if want_state_dense:
-            sd = torch.empty((depth, wc, R, C), dtype=torch.uint8, device=dev)
-            for d in range(depth):
-                ops.onehot_from_code(bufs["parent_code"][d], wc, cube_size, sd[d])
-            outs["state"].append(sd.permute(1, 0, 2, 3).contiguous())
+            sd = torch.empty((depth * p, R, C), dtype=torch.uint8, device=dev)
+            ops.onehot_from_code(bufs["parent_code"].view(depth * tiles, SL, pitch), depth * p, cube_size, sd)
+            outs["state"].append(sd.view(depth, p, R, C)[:, :wc].permute(1, 0, 2, 3).contiguous())
     _lib_status(dev)
     res = {k: torch.cat(v, 0) for k, v in outs.items()}
     res["scramble_count"] = torch.arange(1, depth + 1, dtype=torch.int64, device=dev).expand(n_walks, depth).contiguous()

@@ -48,19 +48,6 @@ struct PermTable {
 template <class T>
 inline constexpr PermTable<T> kPerm{};
 
-// slot touched by action a?  (a slot is touched when any of its stickers moves)
-template <class T>
-constexpr bool slot_moves(int a, int slot) {
-    if (slot < T::NC) {
-        for (int k = 0; k < 3; ++k)
-            if (kPerm<T>.v[a][T::cdef[slot][k]] != T::cdef[slot][k]) return true;
-    } else {
-        for (int k = 0; k < 2; ++k)
-            if (kPerm<T>.v[a][T::edef[slot - T::NC][k]] != T::edef[slot - T::NC][k]) return true;
-    }
-    return false;
-}
-
 // ------------------------------------------------------------------ packed registers
 template <int V>
 struct Pk {
@@ -266,13 +253,106 @@ __device__ __forceinline__ void encode(const Pk<V> (&s)[T::S], Pk<V> (&code)[T::
     });
 }
 
-// code of the child by fixed action A_: untouched slots keep the parent's code
+// ---- codes of a parent AND all its children from one shared set of look-ups -----------------
+// A face turn carries whole cubies: slot p of child a holds the cubie of parent slot q, its three (two)
+// stickers read in a fixed order sigma.  So every child code is LUT[hash(parent colours of slot q in order
+// sigma)] for one of few (q, sigma) pairs: 31 corner + 20 edge pairs cover the 3x3x3 parent and its 12
+// children (13 x 20 = 260 slot codes), 15 cover the 2x2x2 family -- all derived at compile time.
+struct SlotSrc { int q; int j[3]; };
+
+template <class T>
+constexpr SlotSrc corner_src(int a, int p) {   // a < 0: the parent itself
+    SlotSrc r{p, {0, 1, 2}};
+    if (a < 0) return r;
+    for (int q = 0; q < T::NC; ++q)
+        for (int k = 0; k < 3; ++k)
+            if (kPerm<T>.v[a][T::cdef[p][0]] == T::cdef[q][k]) r.q = q;
+    for (int k = 0; k < 3; ++k)
+        for (int j = 0; j < 3; ++j)
+            if (kPerm<T>.v[a][T::cdef[p][k]] == T::cdef[r.q][j]) r.j[k] = j;
+    return r;
+}
+template <class T>
+constexpr SlotSrc edge_src(int a, int e) {
+    SlotSrc r{e, {0, 1, 0}};
+    if (a < 0) return r;
+    for (int q = 0; q < T::NE; ++q)
+        for (int k = 0; k < 2; ++k)
+            if (kPerm<T>.v[a][T::edef[e][0]] == T::edef[q][k]) r.q = q;
+    for (int k = 0; k < 2; ++k)
+        for (int j = 0; j < 2; ++j)
+            if (kPerm<T>.v[a][T::edef[e][k]] == T::edef[r.q][j]) r.j[k] = j;
+    return r;
+}
+constexpr int corner_sigma_id(const SlotSrc &s) { return s.j[0] * 2 + (s.j[1] > s.j[2] ? 1 : 0); }   // 0..5, identity = 0
+constexpr int edge_sigma_id(const SlotSrc &s) { return s.j[0]; }                                      // 0 | 1, identity = 0
+template <class T>
+constexpr bool corner_pair_used(int q, int id) {
+    if (id == 0) return true;
+    for (int a = 0; a < T::A; ++a)
+        for (int p = 0; p < T::NC; ++p) {
+            const SlotSrc s = corner_src<T>(a, p);
+            if (s.q == q && corner_sigma_id(s) == id) return true;
+        }
+    return false;
+}
+template <class T>
+constexpr bool edge_pair_used(int q, int id) {
+    if (id == 0) return true;
+    for (int a = 0; a < T::A; ++a)
+        for (int e = 0; e < T::NE; ++e) {
+            const SlotSrc s = edge_src<T>(a, e);
+            if (s.q == q && edge_sigma_id(s) == id) return true;
+        }
+    return false;
+}
+
+template <class T, int V>
+struct FamilyCodes {
+    Pk<V> c[T::NC][6];
+    Pk<V> e[T::NE > 0 ? T::NE : 1][2];
+};
+
+template <class T, int V>
+__device__ __forceinline__ void family_codes(const Pk<V> (&s)[T::S], FamilyCodes<T, V> &f) {
+    sfor<T::NC>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        sfor<6>([&](auto ic) {
+            constexpr int id = decltype(ic)::value;
+            if constexpr (corner_pair_used<T>(q, id)) {
+                constexpr int j0 = id / 2, r0 = j0 == 0 ? 1 : 0, r1 = j0 == 2 ? 1 : 2;
+                constexpr int j1 = id % 2 ? r1 : r0, j2 = id % 2 ? r0 : r1;
+                constexpr int i0 = T::cdef[q][j0], i1 = T::cdef[q][j1], i2 = T::cdef[q][j2];
+                const Pk<V> h = shl_add(s[i2], 1, shl_add(s[i2], 3, shl_add(s[i1], 1, s[i0])));   // c0 + 2 c1 + 10 c2
+                f.c[q][id] = lut72<T, V, true>(h);
+            }
+        });
+    });
+    sfor<T::NE>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        sfor<2>([&](auto ic) {
+            constexpr int id = decltype(ic)::value;
+            if constexpr (edge_pair_used<T>(q, id)) {
+                constexpr int i0 = T::edef[q][id], i1 = T::edef[q][1 - id];
+                const Pk<V> h = shl_add(s[i1], 1, shl_add(s[i1], 3, s[i0]));                        // c0 + 10 c1
+                f.e[q][id] = lut72<T, V, false>(h);
+            }
+        });
+    });
+}
+
+// codes of child A_ (A_ = -1: the parent) picked out of the family's look-ups
 template <class T, int V, int A_>
-__device__ __forceinline__ void encode_child(const Pk<V> (&child)[T::S], const Pk<V> (&pcode)[T::SLOTS], Pk<V> (&code)[T::SLOTS]) {
+__device__ __forceinline__ void family_pick(const FamilyCodes<T, V> &f, Pk<V> (&code)[T::SLOTS]) {
     sfor<T::SLOTS>([&](auto pc) {
         constexpr int p = decltype(pc)::value;
-        if constexpr (slot_moves<T>(A_, p)) code[p] = encode_slot<T, V, p>(child);
-        else code[p] = pcode[p];
+        if constexpr (p < T::NC) {
+            constexpr SlotSrc src = corner_src<T>(A_, p);
+            code[p] = f.c[src.q][corner_sigma_id(src)];
+        } else {
+            constexpr SlotSrc src = edge_src<T>(A_, p - T::NC);
+            code[p] = f.e[src.q][edge_sigma_id(src)];
+        }
     });
 }
 

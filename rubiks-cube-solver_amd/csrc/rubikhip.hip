@@ -220,7 +220,7 @@ struct ChildOut {
 };
 
 template <class T, int V, int A_, bool CODE>
-__device__ __forceinline__ void emit_child(const Pk<V> (&s)[T::S], const Pk<V> (&pcode)[T::SLOTS], const ChildOut &o, uint32_t lo) {
+__device__ __forceinline__ void emit_child(const Pk<V> (&s)[T::S], const FamilyCodes<T, V> &fam, const ChildOut &o, uint32_t lo) {
     Pk<V> c[T::S];
     fixed_move<T, V, A_>(s, c);
     if (o.children) {
@@ -231,21 +231,21 @@ __device__ __forceinline__ void emit_child(const Pk<V> (&s)[T::S], const Pk<V> (
     if (o.child_solved) st<V, RC_OUT_NT>(o.child_solved + (int64_t)A_ * o.tiles * o.pitch + lo, done_bytes(unsolved<T, V>(c)));
     if constexpr (CODE) {
         Pk<V> cc[T::SLOTS];
-        encode_child<T, V, A_>(c, pcode, cc);
+        family_pick<T, V, A_>(fam, cc);
         uint8_t *row = opaque(o.child_code + (int64_t)A_ * T::SLOTS * o.tiles * o.pitch);
 #pragma unroll
         for (int p = 0; p < T::SLOTS; ++p) { st<V, RC_OUT_NT>(row + lo, cc[p]); row += o.pitch; }
     }
 }
 
-// children part, part+parts, ... of one parent pack; pointers are wave-uniform
+// children part, part+parts, ... of one parent pack; pointers are wave-uniform; `fam` (the family's shared
+// code look-ups) is only read when CODE
 template <class T, int V, bool CODE>
-__device__ __forceinline__ void emit_children(const Pk<V> (&s)[T::S], int part, int parts, const ChildOut &o, uint32_t lo) {
-    Pk<V> pcode[T::SLOTS];
-    if constexpr (CODE) encode<T, V>(s, pcode);
+__device__ __forceinline__ void emit_children(const Pk<V> (&s)[T::S], const FamilyCodes<T, V> &fam, int part, int parts,
+                                              const ChildOut &o, uint32_t lo) {
     sfor<T::A>([&](auto ac) {
         constexpr int a = decltype(ac)::value;
-        if ((a - part) % parts == 0 && a >= part) emit_child<T, V, a, CODE>(s, pcode, o, lo);
+        if ((a - part) % parts == 0 && a >= part) emit_child<T, V, a, CODE>(s, fam, o, lo);
     });
 }
 
@@ -266,7 +266,9 @@ __global__ void __launch_bounds__(kWave) k_expand(ExpandArgs a) {
     const ChildOut o{a.children ? a.children + tile_off(g0, a.pitch_out, a.sh_out, T::S) : nullptr,
                      a.child_solved ? a.child_solved + g0 : nullptr,
                      a.child_code ? a.child_code + tile_off(g0, a.pitch_out, a.sh_out, T::SLOTS) : nullptr, a.pitch_out, a.tiles_out};
-    emit_children<T, V, CODE>(s, part, a.parts, o, lo);
+    FamilyCodes<T, V> fam;
+    if constexpr (CODE) family_codes<T, V>(s, fam);
+    emit_children<T, V, CODE>(s, fam, part, a.parts, o, lo);
 }
 
 // ------------------------------------------------------------------------------- ADI
@@ -318,6 +320,8 @@ __global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
         apply_move<T, V>(s, m, o);
 #pragma unroll
         for (int i = 0; i < T::S; ++i) s[i] = o[i];
+        FamilyCodes<T, V> fam;
+        if constexpr (CODE) family_codes<T, V>(s, fam);
         if (part == 0) {
             if (a.actions_out) st<V, RC_OUT_NT>(a.actions_out + (int64_t)d * a.tiles * a.pitch + w0, act);
             if (a.parents) {
@@ -328,7 +332,7 @@ __global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
             if constexpr (CODE) {
                 if (a.parent_code) {
                     Pk<V> pc[T::SLOTS];
-                    encode<T, V>(s, pc);
+                    family_pick<T, V, -1>(fam, pc);
                     uint8_t *row = opaque(a.parent_code + (int64_t)d * T::SLOTS * a.tiles * a.pitch + tile_off(g0, a.pitch, a.shift, T::SLOTS));
 #pragma unroll
                     for (int p = 0; p < T::SLOTS; ++p) { st<V, RC_OUT_NT>(row + lo, pc[p]); row += a.pitch; }
@@ -340,8 +344,8 @@ __global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
                          a.child_solved ? a.child_solved + (int64_t)d * T::A * wp + g0 : nullptr,
                          a.child_code ? a.child_code + (int64_t)d * T::A * T::SLOTS * wp + tile_off(g0, a.pitch, a.shift, T::SLOTS) : nullptr,
                          a.pitch, a.tiles};
-        if (CODE && co.child_code != nullptr) emit_children<T, V, CODE>(s, part, a.parts, co, lo);
-        else emit_children<T, V, false>(s, part, a.parts, co, lo);
+        if (CODE && co.child_code != nullptr) emit_children<T, V, CODE>(s, fam, part, a.parts, co, lo);
+        else emit_children<T, V, false>(s, fam, part, a.parts, co, lo);
     }
 }
 

@@ -203,6 +203,23 @@ def test_make_env_needs_gpu():
             make_env(torch.device("cpu"), 3)
 
 
+def test_register_gym_entry_point(monkeypatch):
+    import types
+    calls = {}
+    gym = types.ModuleType("gym")
+    envs = types.ModuleType("gym.envs")
+    reg = types.ModuleType("gym.envs.registration")
+    reg.register = lambda id, entry_point: calls.update(id=id, entry_point=entry_point)
+    for name, m in (("gym", gym), ("gym.envs", envs), ("gym.envs.registration", reg)):
+        monkeypatch.setitem(sys.modules, name, m)
+    from rubiks_cube_solver_amd.cube_env import register_gym
+    assert register_gym() == "cube-v0"
+    assert calls == {"id": "cube-v0", "entry_point": "rubiks_cube_solver_amd.cube_env:CubeEnv"}
+    mod_name, cls_name = calls["entry_point"].split(":")
+    import importlib
+    assert getattr(importlib.import_module(mod_name), cls_name).__name__ == "CubeEnv"
+
+
 def test_legacy_scramble_actions(golden):
     from rubiks_cube_solver_amd.vec_env import legacy_scramble_actions
     g = golden("reset_333")

@@ -43,7 +43,8 @@ def _numpy_env_worker(seconds):
 
 def numpy_env_all_cores(seconds=1.5, procs=None):
     import multiprocessing as mp
-    procs = procs or os.cpu_count() or 1
+    # the GPU box gives a one-GPU job a CPU share of 16 cores: size the pool to that, not to the host's 256 threads
+    procs = procs or min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     with mp.get_context("spawn").Pool(procs) as pool:
         rates = pool.map(_numpy_env_worker, [seconds] * procs)
     return float(sum(rates)), procs

@@ -24,6 +24,7 @@
  * xoroshiro128+/splitmix64 specification (DESIGN.md "RNG") so the HIP kernel's action
  * draws can be checked bit for bit.
  */
+#define _POSIX_C_SOURCE 199309L   /* clock_gettime under -std=c11 */
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>

@@ -45,8 +45,14 @@ def numpy_env_all_cores(seconds=1.5, procs=None):
     import multiprocessing as mp
     # the GPU box gives a one-GPU job a CPU share of 16 cores: size the pool to that, not to the host's 256 threads
     procs = procs or min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
-    with mp.get_context("spawn").Pool(procs) as pool:
-        rates = pool.map(_numpy_env_worker, [seconds] * procs)
+    # the workers are plain CPU processes: do not let a profiler's preload (rocprofv3 sets LD_PRELOAD) make each of
+    # them open the GPU
+    saved = {k: os.environ.pop(k) for k in list(os.environ) if k == "LD_PRELOAD" or k.startswith(("ROCP", "ROCPROF"))}
+    try:
+        with mp.get_context("spawn").Pool(procs) as pool:
+            rates = pool.map(_numpy_env_worker, [seconds] * procs)
+    finally:
+        os.environ.update(saved)
     return float(sum(rates)), procs
 
 

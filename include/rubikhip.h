@@ -167,8 +167,11 @@ int rc_read_status(uint32_t *status, void *stream);
 /* Message of the calling thread's last failed call ("" if none). */
 const char *rc_last_error(void);
 
-/* Tuning knob for benchmarks/tests: selects a kernel variant for rc_apply_moves
- * (0 = default).  See DESIGN.md "Kernel variants". */
+/* Tuning knob for benchmarks / tests (0 = the measured defaults; process-global, not thread-safe).  Decimal digits:
+ *   units      pack width of the step kernel: 1,2,3 -> 4,8,16 cubes per lane
+ *   tens       row traffic policy: 1 non-temporal, 2 default-cached
+ *   thousands  (2 digits) parts per walk group for expansion / ADI (1..A)
+ *   100000s    dense one-hot tile: 1 -> 64, 2 -> 256 cubes per workgroup */
 int rc_set_variant(int variant);
 
 #ifdef __cplusplus

@@ -33,3 +33,18 @@ def test_bench_json_line():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["value"] > 1e9                     # the round's floor target: >= 1e9 cube-move steps/s
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal():
+    """The N>1 path (one process per rank, barrier, MAX over ranks, rank 0 prints) rehearsed with two ranks sharing
+    this box's single GPU over gloo; the driver runs the real thing with RCCL on 2/4/8 GPUs."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3", "--backend", "gloo"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d and d["value"] > 1e9

@@ -107,6 +107,15 @@ int rc_scramble(uint8_t *st, int64_t n_cubes, int64_t pitch, int cube_size, int 
                 uint64_t stream_id, int64_t walk_offset, const uint8_t *actions_in, uint8_t *actions_out,
                 int64_t act_pitch, uint8_t *done, float *reward, void *stream);
 
+/* The scramble draws of CubeEnv.reset(seed, k) (cube_env.py:62-68) for n envs at once, bit for bit:
+ * np.random.seed(seeds[i]); np.random.randint(action_dim, size=k_i) of numpy's LEGACY generator
+ * (MT19937 + masked rejection) runs on the device, one env per lane.  k_i = counts[i] (each <= kmax)
+ * or count_uniform when counts is NULL.  actions_out[d * pitch + i] for d < k_i, the no-op value A
+ * for k_i <= d < kmax: ready to be replayed by rc_scramble(actions_in).  pitch >= n, pitch % 16 == 0. */
+int rc_legacy_scramble_actions(const uint32_t *seeds, const int32_t *counts, int count_uniform, int kmax,
+                               int64_t n_envs, int cube_size, uint8_t *actions_out, int64_t pitch,
+                               void *stream);
+
 /* done / reward of the given states, no move.  Replaces isSolved_3 (py333.py:229-233). */
 int rc_is_solved(const uint8_t *st, int64_t n_cubes, int64_t pitch, int cube_size,
                  uint8_t *done, float *reward, void *stream);

@@ -38,6 +38,7 @@ def _declare(L):
     L.rc_fill_solved.argtypes = [vp, i64, i64, i32, vp]
     L.rc_apply_moves.argtypes = [vp, vp, vp, i64, i64, i64, i32, vp, vp, vp, i32, i64, vp]
     L.rc_scramble.argtypes = [vp, i64, i64, i32, i32, u64, u64, i64, vp, vp, i64, vp, vp, vp]
+    L.rc_legacy_scramble_actions.argtypes = [vp, vp, i32, i32, i64, i32, vp, i64, vp]
     L.rc_is_solved.argtypes = [vp, i64, i64, i32, vp, vp, vp]
     L.rc_encode.argtypes = [vp, i64, i64, i32, vp, i32, i64, vp]
     L.rc_onehot_from_code.argtypes = [vp, i64, i64, i32, vp, i32, vp]
@@ -45,7 +46,7 @@ def _declare(L):
     L.rc_adi_generate.argtypes = [u64, u64, i64, i64, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rc_adi_targets.argtypes = [vp, vp, vp, vp, i64, i64, i32, vp, vp, vp, vp]
     L.rc_read_status.argtypes = [vp, vp]
-    for name in ("rc_init", "rc_set_variant", "rc_get_tables", "rc_fill_solved", "rc_apply_moves", "rc_scramble", "rc_is_solved",
+    for name in ("rc_init", "rc_set_variant", "rc_get_tables", "rc_fill_solved", "rc_apply_moves", "rc_scramble", "rc_legacy_scramble_actions", "rc_is_solved",
                  "rc_encode", "rc_onehot_from_code", "rc_expand_children", "rc_adi_generate", "rc_adi_targets",
                  "rc_read_status"):
         getattr(L, name).restype = i32

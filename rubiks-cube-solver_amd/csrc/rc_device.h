@@ -144,6 +144,15 @@ __device__ __forceinline__ Pk<V> action_masks(Pk<V> act, Pk<V> (&m)[T::A]) {
     return bad;
 }
 
+// any bad action among the pack's cubes that really exist (cube index < n)?  Pad columns may hold anything.
+template <int V>
+__device__ __forceinline__ bool any_bad(Pk<V> bad, int64_t n0, int64_t n) {
+    if (n0 + 4 * V <= n) return any(bad);
+    uint32_t o = 0;
+    for (int j = 0; j < 4 * V && n0 + j < n; ++j) o |= (bad.d[j >> 2] >> (8 * (j & 3))) & 0xffu;
+    return o != 0;
+}
+
 // ------------------------------------------------------------------------- the move
 template <class T, int V>
 __device__ __forceinline__ void apply_move(const Pk<V> (&in)[T::S], const Pk<V> (&m)[T::A], Pk<V> (&out)[T::S]) {

@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(StepArgs a) {
         const Pk<V> act = ld_tail<V>(a.actions, n0, a.n, 0);
         Pk<V> m[T::A];
         const Pk<V> bad = action_masks<T, V>(act, m);
-        if (any(bad)) atomicOr(&g_status, RC_STATUS_BAD_ACTION);
+        if (any_bad<V>(bad, n0, a.n)) atomicOr(&g_status, RC_STATUS_BAD_ACTION);
         Pk<V> o[T::S];
         apply_move<T, V>(s, m, o);
 #pragma unroll
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(kDenseBlock) k_step_dense(StepArgs a, E *dense
             const Pk<1> act = ld_tail<1>(a.actions, n0, a.n, 0);
             Pk<1> m[T::A];
             const Pk<1> bad = action_masks<T, 1>(act, m);
-            if (any(bad)) atomicOr(&g_status, RC_STATUS_BAD_ACTION);
+            if (any_bad<1>(bad, n0, a.n)) atomicOr(&g_status, RC_STATUS_BAD_ACTION);
             Pk<1> o[T::S];
             apply_move<T, 1>(s, m, o);
 #pragma unroll
@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
         }
         Pk<V> m[T::A];
         const Pk<V> bad = action_masks<T, V>(act, m);
-        if (any(bad)) atomicOr(&g_status, RC_STATUS_BAD_ACTION);
+        if (any_bad<V>(bad, w0, a.n_walks)) atomicOr(&g_status, RC_STATUS_BAD_ACTION);
         Pk<V> o[T::S];
         apply_move<T, V>(s, m, o);
 #pragma unroll
@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(kWave) k_scramble(ScrambleArgs a) {
         if (a.actions_out) st<V, false>(a.actions_out + (int64_t)d * a.act_pitch + n0, act);
         Pk<V> m[T::A];
         const Pk<V> bad = action_masks<T, V>(act, m);
-        if (any(bad)) atomicOr(&g_status, RC_STATUS_BAD_ACTION);
+        if (any_bad<V>(bad, n0, a.n)) atomicOr(&g_status, RC_STATUS_BAD_ACTION);
         Pk<V> o[T::S];
         apply_move<T, V>(s, m, o);
 #pragma unroll
@@ -410,6 +410,56 @@ __global__ void __launch_bounds__(kWave) k_scramble(ScrambleArgs a) {
         if (a.done) st_tail<V>(a.done, n0, a.n, dn);
         if (a.reward) store_reward<V>(a.reward, n0, a.n, dn);
     }
+}
+
+// ------------------------------------------------- the reference's reset(seed) draws, on the device
+// CubeEnv.reset (cube_env.py:62-68) draws its scramble with numpy's LEGACY global generator:
+//   np.random.seed(seed); np.random.randint(action_dim, size=k)
+// i.e. MT19937 seeded by init_genrand(seed), then for every draw 32-bit outputs masked to the next
+// power of two minus one (15 | 7) and rejected while > action_dim-1.  Reproducing that bit for bit for
+// millions of envs needs the generator itself on the GPU: one lane = one env, its whole 624-word state
+// in LDS (624 x 64 lanes x 4 B = 156 KiB: one wave per CU, column per lane so every access is
+// conflict-free).  All lanes consume one output per iteration, so the state index -- and with it the
+// twist -- stays wave-uniform; lanes only differ in how many outputs they accept.
+constexpr int kMtN = 624, kMtM = 397;
+
+template <int A_>
+__global__ void __launch_bounds__(kWave) k_legacy_actions(const uint32_t *seeds, const int32_t *counts, int count_uniform, int kmax,
+                                                          int64_t n, uint8_t *actions_out, int64_t pitch) {
+    __shared__ uint32_t mt[kMtN * kWave];
+    const int lane = threadIdx.x;
+    const int64_t env = (int64_t)blockIdx.x * kWave + lane;
+    const bool live = env < n;
+    const int want = live ? (counts ? counts[env] : count_uniform) : 0;
+    uint32_t x = live ? seeds[env] : 0u;                       // init_genrand
+    mt[lane] = x;
+    for (int i = 1; i < kMtN; ++i) {
+        x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i;
+        mt[i * kWave + lane] = x;
+    }
+    constexpr uint32_t rng = A_ - 1;
+    constexpr uint32_t mask = rng | rng >> 1 | rng >> 2 | rng >> 3;   // 15 for 12 actions, 7 for 6
+    int idx = kMtN, got = 0;                                   // numpy seeds with mti = 624: the first draw twists
+    while (__any(got < want)) {
+        if (idx == kMtN) {                                     // genrand's in-place twist of the whole state
+            for (int k = 0; k < kMtN; ++k) {
+                const int k1 = k + 1 == kMtN ? 0 : k + 1, km = k + kMtM >= kMtN ? k + kMtM - kMtN : k + kMtM;
+                const uint32_t y = (mt[k * kWave + lane] & 0x80000000u) | (mt[k1 * kWave + lane] & 0x7fffffffu);
+                mt[k * kWave + lane] = mt[km * kWave + lane] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = mt[idx * kWave + lane];
+        ++idx;
+        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+        const uint32_t v = y & mask;
+        if (got < want && v <= rng) {                          // masked rejection (numpy _bounded_integers, legacy path)
+            actions_out[(int64_t)got * pitch + env] = (uint8_t)v;
+            ++got;
+        }
+    }
+    if (live)
+        for (int d = want; d < kmax; ++d) actions_out[(int64_t)d * pitch + env] = (uint8_t)A_;   // pad with the no-op
 }
 
 // ------------------------------------------------------------------------ ADI targets
@@ -677,6 +727,19 @@ int rc_scramble(uint8_t *stp, int64_t n, int64_t pitch, int cube_size, int depth
         RC_HIP(hipGetLastError());
         return RC_OK;
     });
+}
+
+int rc_legacy_scramble_actions(const uint32_t *seeds, const int32_t *counts, int count_uniform, int kmax, int64_t n, int cube_size,
+                                uint8_t *actions_out, int64_t pitch, void *stream) {
+    if (!seeds || !actions_out || n < 0 || kmax < 0 || bad_pitch(pitch, n)) return fail(RC_EINVAL, "rc_legacy_scramble_actions: bad arguments%s");
+    if (!counts && (count_uniform < 0 || count_uniform > kmax)) return fail(RC_EINVAL, "rc_legacy_scramble_actions: count_uniform must be in 0..kmax%s");
+    if (n == 0 || kmax == 0) return RC_OK;
+    const dim3 g((unsigned)((n + kWave - 1) / kWave)), b(kWave);
+    if (cube_size == 3) hipLaunchKernelGGL((k_legacy_actions<12>), g, b, 0, S(stream), seeds, counts, count_uniform, kmax, n, actions_out, pitch);
+    else if (cube_size == 2) hipLaunchKernelGGL((k_legacy_actions<6>), g, b, 0, S(stream), seeds, counts, count_uniform, kmax, n, actions_out, pitch);
+    else return fail(RC_EINVAL, "cube_size must be 2 or 3%s");
+    RC_HIP(hipGetLastError());
+    return RC_OK;
 }
 
 int rc_is_solved(const uint8_t *stp, int64_t n, int64_t pitch, int cube_size, uint8_t *done, float *reward, void *stream) {

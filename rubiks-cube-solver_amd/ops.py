@@ -151,6 +151,33 @@ def scramble(st, n, cube_size, depth, seed=0, stream_id=0, walk_offset=0, action
                             ptr(actions_out), ap, ptr(done), ptr(reward), stream_ptr(st.device)))
 
 
+def legacy_scramble_actions(seeds, cube_size, scramble_count, device=None):
+    """The reference's reset(seed, k) draws for every env, computed on the device (numpy legacy MT19937 +
+    masked rejection, cube_env.py:62-68).  seeds: int tensor / sequence [n] (0 <= seed < 2**32);
+    scramble_count: one int or one int per env.  Returns (actions uint8 [kmax, pitch] with no-op padding, kmax)."""
+    _, A, _ = _size(cube_size)
+    dev = torch.device(device) if device is not None else (seeds.device if isinstance(seeds, torch.Tensor) else torch.device("cuda"))
+    s = torch.as_tensor(seeds)
+    if s.numel() and (int(s.min()) < 0 or int(s.max()) > 0xFFFFFFFF):
+        raise ValueError("Seed must be between 0 and 2**32 - 1")          # numpy's legacy seeding error
+    n = s.numel()
+    s32 = (s.to(torch.int64) & 0xFFFFFFFF).to(torch.int64)
+    s32 = torch.where(s32 >= 2 ** 31, s32 - 2 ** 32, s32).to(torch.int32).to(dev).contiguous()   # raw 32-bit pattern
+    counts = None
+    if isinstance(scramble_count, int):
+        kmax, uniform = scramble_count, scramble_count
+    else:
+        c = torch.as_tensor(scramble_count, dtype=torch.int32)
+        if c.numel() != n:
+            raise ValueError("need one scramble count per env")
+        kmax, uniform, counts = int(c.max()) if n else 0, 0, c.to(dev).contiguous()
+    pitch = _lib.pitch_for(n)
+    out = torch.full((max(kmax, 1), pitch), A, dtype=torch.uint8, device=dev)      # pad columns / rows hold the no-op
+    _lib.init(dev)
+    check(lib().rc_legacy_scramble_actions(ptr(s32), ptr(counts), uniform, kmax, n, cube_size, ptr(out), pitch, stream_ptr(dev)))
+    return out, kmax
+
+
 def is_solved(st, n, cube_size, done=None, reward=None):
     S, _, _ = _size(cube_size)
     pitch = _tiled(st, S, n, "is_solved")

@@ -78,7 +78,7 @@ class VecCubeEnv:
         """Solved, then `scramble_count` random face turns per cube (cube_env.py:50-69).
 
         seeds   : one int per env -> each env i gets exactly the reference's reset(seed=seeds[i],
-                  scramble_count[i]) move sequence (host legacy numpy RNG, state saved/restored);
+                  scramble_count[i]) move sequence; numpy's legacy generator runs on the device;
         actions : explicit uint8 [N, K] moves (overrides seeds); the value `action_dim` is a no-op,
                   so rows may be padded to a common length;
         neither : moves drawn on the device from (seed, stream_id, reset counter) -- reproducible,
@@ -95,13 +95,12 @@ class VecCubeEnv:
         if actions is None and seeds is not None:
             if len(seeds) != n:
                 raise ValueError("need one seed per env")
-            if counts is None:
-                actions = legacy_scramble_actions(seeds, kmax, self.action_dim)
-            else:
-                actions = np.full((n, kmax), self.action_dim, np.uint8)          # pad with the no-op
-                for k in np.unique(counts):
-                    idx = np.nonzero(counts == k)[0]
-                    actions[idx, :k] = legacy_scramble_actions([seeds[i] for i in idx], int(k), self.action_dim)
+            # the reference's np.random.seed(s); randint(A, size=k) per env, generated on the device
+            # (rc_legacy_scramble_actions): bit-exact and independent of the host's global RNG state
+            buf, kk = ops.legacy_scramble_actions(torch.as_tensor(np.asarray(seeds, dtype=np.int64)), self.cube_size,
+                                                  kmax if counts is None else counts.tolist(), device=self.device)
+            ops.scramble(self.stickers, n, self.cube_size, kk, actions_in=buf, done=self.done, reward=self.reward)
+            return self._observe()
         elif counts is not None:
             raise ValueError("per-env scramble counts need seeds (or pad explicit actions with the no-op)")
         if actions is not None:

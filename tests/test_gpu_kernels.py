@@ -462,3 +462,34 @@ def test_sixteen_million_cubes_identities(ops, L):
     ops.apply_moves(tmp, tmp, acts ^ 1, n, 3)
     assert torch.equal(tmp, st)
     assert L.read_status() == 0
+
+
+@pytest.mark.parametrize("cs", CS)
+def test_legacy_numpy_rng_on_device(ops, L, golden, cs):
+    """rc_legacy_scramble_actions == np.random.seed(s); np.random.randint(A, size=k) (numpy's legacy MT19937 with
+    masked rejection), bit for bit: short and long draws (k = 1000 crosses two state twists), per-env counts."""
+    A = A_OF[cs]
+    saved = np.random.get_state()
+    try:
+        seeds = [0, 1, 5, 10, 90, 12345, 777, 2 ** 31, 2 ** 32 - 1] + list(range(100, 100 + 150))
+        for k in (1, 5, 30, 227, 1000):
+            buf, kk = ops.legacy_scramble_actions(torch.tensor(seeds, dtype=torch.int64), cs, k, device="cuda")
+            got = buf[:k, :len(seeds)].cpu().numpy().T
+            for i, s in enumerate(seeds):
+                np.random.seed(s)
+                assert (got[i] == np.random.randint(A, size=k)).all(), (s, k)
+        counts = [1 + (7 * i) % 40 for i in range(len(seeds))]
+        buf, kk = ops.legacy_scramble_actions(torch.tensor(seeds, dtype=torch.int64), cs, counts, device="cuda")
+        got = buf[:, :len(seeds)].cpu().numpy().T
+        assert kk == max(counts)
+        for i, (s, k) in enumerate(zip(seeds, counts)):
+            np.random.seed(s)
+            assert (got[i, :k] == np.random.randint(A, size=k)).all() and (got[i, k:kk] == A).all()
+    finally:
+        np.random.set_state(saved)
+    if cs == 3:
+        g = golden("reset_333")                                   # the reference's own reset(seed, k) draws
+        buf, _ = ops.legacy_scramble_actions(torch.tensor([int(s) for s in g["seeds"]]), 3, 30, device="cuda")
+        assert (buf[:30, :len(g["seeds"])].cpu().numpy().T == g["actions"][:, 29, :]).all()
+    with pytest.raises(ValueError):
+        ops.legacy_scramble_actions(torch.tensor([-1]), cs, 3, device="cuda")

@@ -97,7 +97,8 @@ class VecCubeEnv:
                 raise ValueError("need one seed per env")
             # the reference's np.random.seed(s); randint(A, size=k) per env, generated on the device
             # (rc_legacy_scramble_actions): bit-exact and independent of the host's global RNG state
-            buf, kk = ops.legacy_scramble_actions(torch.as_tensor(np.asarray(seeds, dtype=np.int64)), self.cube_size,
+            s_t = seeds if isinstance(seeds, torch.Tensor) else torch.as_tensor(np.asarray(seeds, dtype=np.int64))
+            buf, kk = ops.legacy_scramble_actions(s_t, self.cube_size,
                                                   kmax if counts is None else counts.tolist(), device=self.device)
             ops.scramble(self.stickers, n, self.cube_size, kk, actions_in=buf, done=self.done, reward=self.reward)
             return self._observe()

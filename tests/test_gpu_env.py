@@ -203,6 +203,8 @@ def test_vec_env_seeded_reset_is_reference_reset(mod, golden):
     assert (np.random.get_state()[1] == before).all()
     with pytest.raises(UnboundLocalError):
         env.reset(scramble_count=0)
+    env.reset(seeds=torch.tensor(seeds, device="cuda"), scramble_count=30)       # seeds may already live on the device
+    assert (env.sim_cube.cpu().numpy() == g["stickers"][:, 29]).all()
 
 
 # ------------------------------------------------------------------ no-op, rollouts (N3), MCTS (N2)

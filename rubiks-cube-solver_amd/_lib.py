@@ -13,7 +13,7 @@ import threading
 import torch  # must be imported before the library so both share one HIP runtime (libamdhip64.so.7)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librubikhip.so")
+LIB_PATH = os.environ.get("RUBIKHIP_LIB") or os.path.join(_HERE, "librubikhip.so")   # env override: A/B builds in experiments
 
 FMT_NONE, FMT_CODE, FMT_U8, FMT_F16, FMT_F32, FMT_BF16 = 0, 1, 2, 3, 4, 5
 _FMT_DTYPE = {FMT_U8: torch.uint8, FMT_F16: torch.float16, FMT_F32: torch.float32, FMT_BF16: torch.bfloat16}

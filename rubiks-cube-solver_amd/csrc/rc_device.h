@@ -99,20 +99,24 @@ __device__ __forceinline__ void st(uint8_t *p, Pk<V> v) {
     if constexpr (NT) __builtin_nontemporal_store(u, reinterpret_cast<U *>(p));
     else *reinterpret_cast<U *>(p) = u;
 }
-// [n] arrays without padding (actions, done): vector access when the whole pack is inside, bytes otherwise
+// [n] arrays without padding (actions, done): vector access when the whole pack is inside, bytes otherwise.
+// The byte paths are fully unrolled with static register indices (a run-time index would push the pack into
+// scratch / LDS and slow the common path down as well).
 template <int V>
 __device__ __forceinline__ Pk<V> ld_tail(const uint8_t *base, int64_t n0, int64_t n, uint32_t fill) {
     if (n0 + 4 * V <= n) return ld<V, false>(base + n0);
     Pk<V> r = splat<V>(fill * 0x01010101u);
-    for (int j = 0; j < 4 * V && n0 + j < n; ++j) {
-        r.d[j >> 2] = (r.d[j >> 2] & ~(0xffu << (8 * (j & 3)))) | ((uint32_t)base[n0 + j] << (8 * (j & 3)));
-    }
+#pragma unroll
+    for (int j = 0; j < 4 * V; ++j)
+        if (n0 + j < n) r.d[j >> 2] = (r.d[j >> 2] & ~(0xffu << (8 * (j & 3)))) | ((uint32_t)base[n0 + j] << (8 * (j & 3)));
     return r;
 }
 template <int V>
 __device__ __forceinline__ void st_tail(uint8_t *base, int64_t n0, int64_t n, Pk<V> v) {
     if (n0 + 4 * V <= n) { st<V, false>(base + n0, v); return; }
-    for (int j = 0; j < 4 * V && n0 + j < n; ++j) base[n0 + j] = (uint8_t)(v.d[j >> 2] >> (8 * (j & 3)));
+#pragma unroll
+    for (int j = 0; j < 4 * V; ++j)
+        if (n0 + j < n) base[n0 + j] = (uint8_t)(v.d[j >> 2] >> (8 * (j & 3)));
 }
 
 // ---------------------------------------------------------------------- action masks
@@ -147,9 +151,14 @@ __device__ __forceinline__ Pk<V> action_masks(Pk<V> act, Pk<V> (&m)[T::A]) {
 // any bad action among the pack's cubes that really exist (cube index < n)?  Pad columns may hold anything.
 template <int V>
 __device__ __forceinline__ bool any_bad(Pk<V> bad, int64_t n0, int64_t n) {
-    if (n0 + 4 * V <= n) return any(bad);
+    const int64_t r = n - n0;                                  // cubes of this pack inside the batch (> 0)
+    if (r >= 4 * V) return any(bad);
     uint32_t o = 0;
-    for (int j = 0; j < 4 * V && n0 + j < n; ++j) o |= (bad.d[j >> 2] >> (8 * (j & 3))) & 0xffu;
+    RC_V {
+        const int rk = (int)r - 4 * k;                         // valid bytes of dword k
+        const uint32_t mk = rk >= 4 ? 0xffffffffu : rk <= 0 ? 0u : ((1u << (8 * rk)) - 1u);
+        o |= bad.d[k] & mk;
+    }
     return o != 0;
 }
 

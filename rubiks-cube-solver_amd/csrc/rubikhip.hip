@@ -74,19 +74,19 @@ __device__ __forceinline__ void store_reward(float *reward, int64_t n0, int64_t 
             *reinterpret_cast<float4 *>(reward + n0 + 4 * k) = f;
         }
     } else {
-        for (int j = 0; j < 4 * V && n0 + j < n; ++j) reward[n0 + j] = reward_of(dn.d[j >> 2], j & 3);
+#pragma unroll
+        for (int j = 0; j < 4 * V; ++j)
+            if (n0 + j < n) reward[n0 + j] = reward_of(dn.d[j >> 2], j & 3);
     }
 }
 
 // One lane = 4*V consecutive cubes.  MOVE: apply actions; STORE: write the state rows;
-// CODE: write the compact code rows; NT: non-temporal row traffic.
-template <class T, int V, bool MOVE, bool STORE, bool CODE, bool NT, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) k_step(StepArgs a) {
-    // wave-uniform part of the cube index in SGPRs, 32-bit lane offset in one VGPR
-    const int64_t g0 = (int64_t)blockIdx.x * (BLOCK * 4 * V);
-    const uint32_t lo = threadIdx.x * (4 * V);
+// CODE: write the compact code rows; NT: non-temporal row traffic.  FULL: every pack of the wave lies
+// inside the batch (all but the last wave): no per-byte tail paths in the instruction stream.
+template <class T, int V, bool MOVE, bool STORE, bool CODE, bool NT, bool FULL>
+__device__ __forceinline__ void step_body(const StepArgs &a, int64_t g0, uint32_t lo) {
     const int64_t n0 = g0 + lo;
-    if (n0 >= a.n) return;
+    const int64_t n = FULL ? n0 + 4 * V : a.n;               // FULL: the tail helpers take their vector path
     Pk<V> s[T::S];
     {
         const uint8_t *row = a.in + tile_off(g0, a.pitch_in, a.sh_in, T::S);
@@ -94,10 +94,10 @@ __global__ void __launch_bounds__(BLOCK) k_step(StepArgs a) {
         for (int i = 0; i < T::S; ++i) { s[i] = ld<V, NT>(row + lo); row += a.pitch_in; }
     }
     if constexpr (MOVE) {
-        const Pk<V> act = ld_tail<V>(a.actions, n0, a.n, 0);
+        const Pk<V> act = ld_tail<V>(a.actions, n0, n, 0);
         Pk<V> m[T::A];
         const Pk<V> bad = action_masks<T, V>(act, m);
-        if (any_bad<V>(bad, n0, a.n)) atomicOr(&g_status, RC_STATUS_BAD_ACTION);
+        if (any_bad<V>(bad, n0, n)) atomicOr(&g_status, RC_STATUS_BAD_ACTION);
         Pk<V> o[T::S];
         apply_move<T, V>(s, m, o);
 #pragma unroll
@@ -110,8 +110,8 @@ __global__ void __launch_bounds__(BLOCK) k_step(StepArgs a) {
     }
     if (a.done != nullptr || a.reward != nullptr) {
         const Pk<V> dn = done_bytes(unsolved<T, V>(s));
-        if (a.done) st_tail<V>(a.done, n0, a.n, dn);
-        if (a.reward) store_reward<V>(a.reward, n0, a.n, dn);
+        if (a.done) st_tail<V>(a.done, n0, n, dn);
+        if (a.reward) store_reward<V>(a.reward, n0, n, dn);
     }
     if constexpr (CODE) {
         Pk<V> c[T::SLOTS];
@@ -119,6 +119,18 @@ __global__ void __launch_bounds__(BLOCK) k_step(StepArgs a) {
         uint8_t *row = a.code + tile_off(g0, a.code_pitch, a.sh_code, T::SLOTS);
 #pragma unroll
         for (int p = 0; p < T::SLOTS; ++p) { st<V, NT>(row + lo, c[p]); row += a.code_pitch; }
+    }
+}
+
+template <class T, int V, bool MOVE, bool STORE, bool CODE, bool NT, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_step(StepArgs a) {
+    // wave-uniform part of the cube index in SGPRs, 32-bit lane offset in one VGPR
+    const int64_t g0 = (int64_t)blockIdx.x * (BLOCK * 4 * V);
+    const uint32_t lo = threadIdx.x * (4 * V);
+    if (g0 + BLOCK * 4 * V <= a.n) {                           // uniform: the whole workgroup is inside the batch
+        step_body<T, V, MOVE, STORE, CODE, NT, true>(a, g0, lo);
+    } else if (g0 + lo < a.n) {
+        step_body<T, V, MOVE, STORE, CODE, NT, false>(a, g0, lo);
     }
 }
 

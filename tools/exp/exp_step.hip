@@ -13,9 +13,16 @@ using T = Cube3;
 struct Args { const uint8_t *in; uint8_t *out; const uint8_t *act; uint8_t *done; int64_t n, pitch, tile; };
 
 // address of row i for the lane: plain SoA (tile == 0) or tiled SoA [n/tile][S][tile]
-template <int V, bool MOVE, bool NT, int BLOCK, bool TILED, bool INPLACE = false, int WPE = 1>
+template <int V, bool MOVE, bool NT, int BLOCK, bool TILED, bool INPLACE = false, int WPE = 1, int XCD = 0>
 __global__ void __launch_bounds__(BLOCK, WPE) k_step(Args a) {
-    const int64_t g0 = (int64_t)blockIdx.x * (BLOCK * 4 * V);
+    int64_t blk = blockIdx.x;
+    if constexpr (XCD > 0) {
+        // XCD-aware: blocks b, b+8, ... run on one XCD (round-robin dispatch): give each XCD whole runs of XCD
+        // consecutive blocks so that one L2 sees contiguous row segments
+        const int64_t x = blk % 8, j = blk / 8;
+        blk = (j / XCD) * (8 * XCD) + x * XCD + (j % XCD);
+    }
+    const int64_t g0 = blk * (BLOCK * 4 * V);
     const uint32_t lo = threadIdx.x * (4 * V);
     const int64_t n0 = g0 + lo;
     if (n0 >= a.n) return;
@@ -173,12 +180,17 @@ int main(int argc, char **argv) {
         const int64_t blocks = n / (64 * 4 * V); \
         double t = timeit([&] { a.in = buf[0]; a.out = buf[1]; hipLaunchKernelGGL((k_step<V, true, true, 64, true, INP, WPE>), dim3(blocks), dim3(64), 0, 0, a); std::swap(buf[0], buf[1]); }); \
         report(NAME, t, bytes); }
+#define RUNX(XC, NAME) { \
+        Args a{buf[0], buf[1], act, done, n, pitch, 32768}; \
+        const int64_t blocks = n / (64 * 4 * 2); \
+        double t = timeit([&] { a.in = buf[0]; a.out = buf[1]; hipLaunchKernelGGL((k_step<2, true, true, 64, true, false, 1, XC>), dim3(blocks), dim3(64), 0, 0, a); std::swap(buf[0], buf[1]); }); \
+        report(NAME, t, bytes); }
         for (int rep = 0; rep < 3; ++rep) {
-            RUN(2, true, true, 64, true, 32768, "step V2 nt b64 tiled32768");
-            RUN(2, true, true, 128, true, 32768, "step V2 nt b128 tiled32768");
-            RUN(2, true, true, 256, true, 32768, "step V2 nt b256 tiled32768");
-            RUNI(2, false, 2, "step V2 nt b64 wpe2 tiled32768");
-            RUNI(2, false, 3, "step V2 nt b64 wpe3 tiled32768");
+            RUNX(0, "step V2 nt tiled32768 plain block order");
+            RUNX(2, "step V2 nt tiled32768 xcd runs of 2");
+            RUNX(8, "step V2 nt tiled32768 xcd runs of 8");
+            RUNX(64, "step V2 nt tiled32768 xcd runs of 64 (= 1 tile)");
+            RUNX(512, "step V2 nt tiled32768 xcd runs of 512");
         }
     }
     return 0;

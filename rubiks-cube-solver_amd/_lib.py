@@ -77,7 +77,12 @@ def init(device: torch.device):
     """rc_init for the tensor's device (once per device per process)."""
     if device.type != "cuda":
         raise RubikHipError(f"cube tensors must live on a HIP device, got {device}")
-    idx = device.index if device.index is not None else torch.cuda.current_device()
+    cur = torch.cuda.current_device()
+    idx = device.index if device.index is not None else cur
+    if idx != cur:
+        # kernels are launched for the CURRENT device; one process per GPU is the deployment model
+        raise RubikHipError(f"tensor lives on cuda:{idx} but cuda:{cur} is current: call torch.cuda.set_device({idx}) "
+                            f"(or use `with torch.cuda.device({idx}):`) around cube operations")
     if idx not in _inited:
         check(lib().rc_init(idx))
         _inited.add(idx)

@@ -20,8 +20,11 @@
  *   - actions are uint8 in the env's action order U,U',F,F',R,R'[,D,D',B,B',L,L']
  *     (gym-cube/gym_cube/envs/cube_env.py:24-28); A = 12 | 6.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
- *     stream-ordered, never synchronise (except rc_read_status / rc_get_tables), are
- *     re-entrant, and keep no mutable state besides the per-device status word.
+ *     stream-ordered, never synchronise (except rc_read_status, rc_facade_step(wait=1) and
+ *     rc_get_tables), are re-entrant, and keep no mutable state besides the per-device status word
+ *     (one word per DEVICE, shared by all streams).
+ *   - Row offsets inside one tile are 32-bit scalar offsets of buffer instructions: rows * pitch
+ *     must stay below 2^32 (a single tile of more than ~79 M 3x3x3 cubes has to be split into tiles).
  *   - Return value: RC_OK or a negative RC_E* code; rc_last_error() gives the message of
  *     the calling thread's last failure.  Nothing is thrown across the ABI.
  *   - The action value A itself (12 | 6) is a NO-OP: the cube is left unchanged (its done /
@@ -97,6 +100,20 @@ int rc_fill_solved(uint8_t *st, int64_t n_cubes, int64_t pitch, int cube_size, v
 int rc_apply_moves(const uint8_t *in, uint8_t *out, const uint8_t *actions, int64_t n_cubes,
                    int64_t pitch_in, int64_t pitch_out, int cube_size, float *reward,
                    uint8_t *done, void *onehot, int fmt, int64_t code_pitch, void *stream);
+/* Same with a per-call tuning override (see "Tuning override" at the end; 0 = rc_apply_moves). */
+int rc_apply_moves_ex(const uint8_t *in, uint8_t *out, const uint8_t *actions, int64_t n_cubes,
+                      int64_t pitch_in, int64_t pitch_out, int cube_size, float *reward,
+                      uint8_t *done, void *onehot, int fmt, int64_t code_pitch, void *stream, int variant);
+
+/* CubeEnv.step for ONE cube with the lowest host latency (cube_env.py:71-111; the batch-1 facade):
+ * st is a device state buffer whose cube 0 is stepped in place (sticker s at st[s * pitch]); the action
+ * travels by value; the kernel writes into `host_out`, 512 bytes of HOST-MAPPED pinned memory
+ * (hipHostMalloc / torch pin_memory): [0, R*C) the dense uint8 one-hot of the new state, [496] done,
+ * [504..507] `seq` (non-zero, written last after a system-scope fence).  wait != 0: returns once `seq`
+ * is visible in host_out (spin on the flag; no stream synchronisation, no copies); wait == 0: returns
+ * after the launch and the caller polls host_out itself.  Out-of-range actions set RC_STATUS_BAD_ACTION. */
+int rc_facade_step(uint8_t *st, int64_t pitch, int cube_size, int action, uint8_t *host_out,
+                   uint32_t seq, int wait, void *stream);
 
 /* `depth` moves applied in place to every cube: the scramble loop of CubeEnv.reset
  * (cube_env.py:65-67) for n_cubes cubes at once.  actions_in[d * act_pitch + n] replays given
@@ -109,8 +126,8 @@ int rc_scramble(uint8_t *st, int64_t n_cubes, int64_t pitch, int cube_size, int 
 
 /* The scramble draws of CubeEnv.reset(seed, k) (cube_env.py:62-68) for n envs at once, bit for bit:
  * np.random.seed(seeds[i]); np.random.randint(action_dim, size=k_i) of numpy's LEGACY generator
- * (MT19937 + masked rejection) runs on the device, one env per lane.  k_i = counts[i] (each <= kmax)
- * or count_uniform when counts is NULL.  actions_out[d * pitch + i] for d < k_i, the no-op value A
+ * (MT19937 + masked rejection) runs on the device, one env per lane.  k_i = counts[i] (device memory;
+ * values outside 0..kmax are clamped to that range) or count_uniform when counts is NULL.  actions_out[d * pitch + i] for d < k_i, the no-op value A
  * for k_i <= d < kmax: ready to be replayed by rc_scramble(actions_in).  pitch >= n, pitch % 16 == 0. */
 int rc_legacy_scramble_actions(const uint32_t *seeds, const int32_t *counts, int count_uniform, int kmax,
                                int64_t n_envs, int cube_size, uint8_t *actions_out, int64_t pitch,
@@ -139,6 +156,9 @@ int rc_onehot_from_code(const uint8_t *code, int64_t n_cubes, int64_t code_pitch
 int rc_expand_children(const uint8_t *in, int64_t n_cubes, int64_t pitch_in, int cube_size,
                        uint8_t *children, uint8_t *child_solved, uint8_t *child_code,
                        int64_t pitch_out, void *stream);
+int rc_expand_children_ex(const uint8_t *in, int64_t n_cubes, int64_t pitch_in, int cube_size,
+                          uint8_t *children, uint8_t *child_solved, uint8_t *child_code,
+                          int64_t pitch_out, void *stream, int variant);
 
 /* ADI scramble generator: n_walks random walks of `depth` moves from the solved cube, each
  * step expanded to all A children.  Replaces the env work of CubeEnv.get_random_samples
@@ -159,6 +179,11 @@ int rc_adi_generate(uint64_t seed, uint64_t stream_id, int64_t walk_offset, int6
                     int depth, int cube_size, int64_t pitch, const uint8_t *actions_in,
                     uint8_t *actions_out, uint8_t *parents, uint8_t *parent_code,
                     uint8_t *children, uint8_t *child_code, uint8_t *child_solved, void *stream);
+int rc_adi_generate_ex(uint64_t seed, uint64_t stream_id, int64_t walk_offset, int64_t n_walks,
+                       int depth, int cube_size, int64_t pitch, const uint8_t *actions_in,
+                       uint8_t *actions_out, uint8_t *parents, uint8_t *parent_code,
+                       uint8_t *children, uint8_t *child_code, uint8_t *child_solved, void *stream,
+                       int variant);
 
 /* ADI target assembly for `n` parents with A children each.
  * Replaces cube_env.py:229-232,239-251:
@@ -170,18 +195,21 @@ int rc_adi_targets(const float *child_value, const uint8_t *child_solved, const 
                    const double *weight, int64_t n, int64_t pitch, int cube_size,
                    float *target_value, int32_t *target_policy, double *error, void *stream);
 
-/* Read-and-clear the device status word (synchronises `stream`). */
+/* Read-and-clear the device status word: ONE atomic exchange on the device, ordered after the work queued
+ * on `stream` (which it synchronises).  The word is per device, not per stream: a bit set by a kernel
+ * that is still running on another stream is not lost -- it shows up in a later read. */
 int rc_read_status(uint32_t *status, void *stream);
 
 /* Message of the calling thread's last failed call ("" if none). */
 const char *rc_last_error(void);
 
-/* Tuning knob for benchmarks / tests (0 = the measured defaults; process-global, not thread-safe).  Decimal digits:
- *   units      pack width of the step kernel: 1,2,3 -> 4,8,16 cubes per lane
- *   tens       row traffic policy: 1 non-temporal, 2 default-cached
- *   thousands  (2 digits) parts per walk group for expansion / ADI (1..A)
+/* Tuning override of the *_ex entry points (benchmarks and tests that must reach every kernel
+ * instantiation; there is NO process-global knob).  0 = the measured defaults.  Decimal digits:
+ *   units      pack width: 1,2,3 -> 4,8,16 cubes per lane (expansion / ADI: 1,2 only)
+ *   tens       row-traffic policy of the step kernel: 1 stream in / stream out, 2 default-cached,
+ *              3 stream in / keep the output in the Infinity Cache
+ *   thousands  (2 digits) parts per walk group for expansion / ADI (1..A, rounded up to a divisor of A)
  *   100000s    dense one-hot tile: 1 -> 64, 2 -> 256 cubes per workgroup */
-int rc_set_variant(int variant);
 
 #ifdef __cplusplus
 }

@@ -119,6 +119,36 @@ __device__ __forceinline__ void st_tail(uint8_t *base, int64_t n0, int64_t n, Pk
         if (n0 + j < n) base[n0 + j] = (uint8_t)(v.d[j >> 2] >> (8 * (j & 3)));
 }
 
+// ------------------------------------------------------------- buffer (SRD) row access
+// Row traffic goes through raw BUFFER instructions: a 4-SGPR resource descriptor built from a
+// WAVE-UNIFORM base pointer, the lane's 32-bit byte offset in one VGPR (voffset) and the row offset in an
+// SGPR (soffset).  No per-access 64-bit VALU address arithmetic, no address VGPR pairs, and the cache
+// policy is an immediate of the instruction (aux bits on gfx950: 1 = sc0, 2 = nt, 16 = sc1).
+// Measured on MI355X (tools/exp/exp_write3.hip, exp_step2.hip; profiles/r02_design_ab.json):
+//   write-once output streams  : sc0 sc1 nt (19) -- the ADI child stream 7.2 TB/s against 5.3 default-cached
+//   inputs read once           : nt (2)
+//   outputs the next launch reads (state ping-pong up to the Infinity Cache size): sc0 sc1 (17)
+constexpr int kAuxCached = 0, kAuxStreamLoad = 2, kAuxKeepStore = 17, kAuxStreamStore = 19;
+
+// soffset is 32 bits: callers keep (rows * pitch) below 2^32 (checked on the host).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void *wave_uniform_base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(wave_uniform_base), 0, 0xffffffff, 0x00020000);
+}
+template <int V, int AUX>
+__device__ __forceinline__ Pk<V> bld(__amdgpu_buffer_rsrc_t r, uint32_t lo, uint32_t so) {
+    Pk<V> p;
+    if constexpr (V == 1) p.d[0] = __builtin_amdgcn_raw_buffer_load_b32(r, lo, so, AUX);
+    else if constexpr (V == 2) { const u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(r, lo, so, AUX); p.d[0] = u[0]; p.d[1] = u[1]; }
+    else { const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, lo, so, AUX); p.d[0] = u[0]; p.d[1] = u[1]; p.d[2] = u[2]; p.d[3] = u[3]; }
+    return p;
+}
+template <int V, int AUX>
+__device__ __forceinline__ void bst(__amdgpu_buffer_rsrc_t r, uint32_t lo, uint32_t so, Pk<V> p) {
+    if constexpr (V == 1) __builtin_amdgcn_raw_buffer_store_b32(p.d[0], r, lo, so, AUX);
+    else if constexpr (V == 2) { const u32x2 u = {p.d[0], p.d[1]}; __builtin_amdgcn_raw_buffer_store_b64(u, r, lo, so, AUX); }
+    else { const u32x4 u = {p.d[0], p.d[1], p.d[2], p.d[3]}; __builtin_amdgcn_raw_buffer_store_b128(u, r, lo, so, AUX); }
+}
+
 // ---------------------------------------------------------------------- action masks
 // m[a] selects (per byte) the cubes whose action is a.  Only the bits a sticker can use
 // (0..2) are guaranteed: mask bytes are 0x07 (a < 8) or 0xff (a >= 8); a stray 0x80 can show
@@ -214,6 +244,76 @@ __device__ __forceinline__ Pk<V> done_bytes(Pk<V> uns) {
 // reward of cube j of a pack: +1.0f if done else -1.0f  (cube_env.py:99-104)
 __device__ __forceinline__ float reward_of(uint32_t done_dword, int byte) {
     return __uint_as_float(0xBF800000u ^ (((done_dword >> (8 * byte)) & 1u) << 31));
+}
+
+// ---- solved flags of all A children of a REACHABLE parent (ADI walks start from the solved cube) ------
+// child a = move_a(parent) is solved  <=>  parent == K_a := move_a^-1(solved), a constant state that differs
+// from the solved cube only on the ring of face a/2 (the 4 strips around the turned face).  On reachable
+// states "every face equals its first sticker" (py333.py:229-233) is the same as "equals the solved cube":
+// 3x3x3 centres never move, the 2x2x2 DLB cubie is fixed.  So
+//   unsolved(child a) = OR_{j not in ring} (s[j] ^ solved[j])  |  OR_{j in ring} (s[j] ^ K_a[j])
+// and the first term is shared between children: stickers are grouped by the set of rings they belong to
+// (their signature), one OR per class, one OR of classes per face.  ~370 VALU ops per pack for the 12 flags
+// of a 3x3x3 parent instead of 12 x 96.  rc_expand_children (arbitrary colourings allowed) keeps the
+// literal per-child test.
+template <class T>
+struct RingInfo {
+    uint8_t K[T::A][T::S];
+    uint8_t sig[T::S];      // bit f set: sticker j lies in the ring of face f
+    constexpr RingInfo() : K{}, sig{} {
+        for (int a = 0; a < T::A; ++a)
+            for (int i = 0; i < T::S; ++i) K[a][kPerm<T>.v[a][i]] = (uint8_t)(i / T::FACE);   // child[i] = parent[perm[a][i]] must be solved[i]
+        for (int j = 0; j < T::S; ++j)
+            for (int a = 0; a < T::A; ++a)
+                if (K[a][j] != j / T::FACE) sig[j] |= (uint8_t)(1u << (a / 2));
+    }
+    constexpr bool sig_used(int c) const {
+        for (int j = 0; j < T::S; ++j)
+            if (sig[j] == c) return true;
+        return false;
+    }
+};
+template <class T>
+inline constexpr RingInfo<T> kRing{};
+
+template <class T, int V>
+struct ChildFlags {
+    Pk<V> not_ring[T::A / 2];   // per face: OR of (s ^ solved) over the stickers outside its ring
+};
+template <class T, int V>
+__device__ __forceinline__ void child_flags_prepare(const Pk<V> (&s)[T::S], ChildFlags<T, V> &cf) {
+    constexpr int NSIG = 1 << (T::A / 2);
+    Pk<V> cls[NSIG];
+    sfor<NSIG>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        if constexpr (kRing<T>.sig_used(c)) {
+            Pk<V> acc = splat<V>(0);
+            sfor<T::S>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (kRing<T>.sig[j] == c) acc = acc | (s[j] ^ splat<V>((uint32_t)(j / T::FACE) * 0x01010101u));
+            });
+            cls[c] = acc;
+        }
+    });
+    sfor<T::A / 2>([&](auto fc) {
+        constexpr int f = decltype(fc)::value;
+        Pk<V> acc = splat<V>(0);
+        sfor<NSIG>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            if constexpr (kRing<T>.sig_used(c) && !((c >> f) & 1)) acc = acc | cls[c];
+        });
+        cf.not_ring[f] = acc;
+    });
+}
+// per byte: non-zero iff child A_ of the (reachable) parent s is NOT solved
+template <class T, int V, int A_>
+__device__ __forceinline__ Pk<V> child_unsolved(const Pk<V> (&s)[T::S], const ChildFlags<T, V> &cf) {
+    Pk<V> acc = cf.not_ring[A_ / 2];
+    sfor<T::S>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr ((kRing<T>.sig[j] >> (A_ / 2)) & 1) acc = acc | (s[j] ^ splat<V>((uint32_t)kRing<T>.K[A_][j] * 0x01010101u));
+    });
+    return acc;
 }
 
 // ------------------------------------------------------------------------- one-hot code

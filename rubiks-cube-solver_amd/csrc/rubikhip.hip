@@ -23,8 +23,10 @@
 
 using namespace rc;
 
-#ifndef RC_OUT_NT
-#define RC_OUT_NT false  // expansion / ADI output stores: default-cached measured 1.5-3 % faster than non-temporal (tools/exp/adi_ab.py)
+// Cache policy of the write-once expansion / ADI output streams (rc_device.h "buffer row access"): system-scope
+// non-temporal stores; A/B against default-cached and plain nt in profiles/r02_design_ab.json.
+#ifndef RC_OUT_AUX
+#define RC_OUT_AUX kAuxStreamStore
 #endif
 
 namespace {
@@ -80,18 +82,30 @@ __device__ __forceinline__ void store_reward(float *reward, int64_t n0, int64_t 
     }
 }
 
+// Row-traffic policy of the step kernel (aux bits in rc_device.h):
+//   POL 0  everything default-cached: the launch's working set fits the 256 MiB Infinity Cache;
+//   POL 1  inputs streamed (nt), outputs written through but kept (sc0 sc1): the next launch reads what this one
+//          wrote and the output alone still fits the Infinity Cache (state ping-pong of 2^22 cubes);
+//   POL 2  inputs streamed, outputs streamed (sc0 sc1 nt): beyond that.
+template <int POL> struct RowPolicy;
+template <> struct RowPolicy<0> { static constexpr int LD = kAuxCached, ST = kAuxCached; };
+template <> struct RowPolicy<1> { static constexpr int LD = kAuxStreamLoad, ST = kAuxKeepStore; };
+template <> struct RowPolicy<2> { static constexpr int LD = kAuxStreamLoad, ST = kAuxStreamStore; };
+
 // One lane = 4*V consecutive cubes.  MOVE: apply actions; STORE: write the state rows;
-// CODE: write the compact code rows; NT: non-temporal row traffic.  FULL: every pack of the wave lies
+// CODE: write the compact code rows.  FULL: every pack of the wave lies
 // inside the batch (all but the last wave): no per-byte tail paths in the instruction stream.
-template <class T, int V, bool MOVE, bool STORE, bool CODE, bool NT, bool FULL>
+template <class T, int V, bool MOVE, bool STORE, bool CODE, int POL, bool FULL>
 __device__ __forceinline__ void step_body(const StepArgs &a, int64_t g0, uint32_t lo) {
+    using P = RowPolicy<POL>;
     const int64_t n0 = g0 + lo;
     const int64_t n = FULL ? n0 + 4 * V : a.n;               // FULL: the tail helpers take their vector path
     Pk<V> s[T::S];
     {
-        const uint8_t *row = a.in + tile_off(g0, a.pitch_in, a.sh_in, T::S);
+        const __amdgpu_buffer_rsrc_t r = make_srd(a.in + tile_off(g0, a.pitch_in, a.sh_in, T::S));
+        const uint32_t rs = (uint32_t)a.pitch_in;
 #pragma unroll
-        for (int i = 0; i < T::S; ++i) { s[i] = ld<V, NT>(row + lo); row += a.pitch_in; }
+        for (int i = 0; i < T::S; ++i) s[i] = bld<V, P::LD>(r, lo, i * rs);
     }
     if constexpr (MOVE) {
         const Pk<V> act = ld_tail<V>(a.actions, n0, n, 0);
@@ -104,9 +118,10 @@ __device__ __forceinline__ void step_body(const StepArgs &a, int64_t g0, uint32_
         for (int i = 0; i < T::S; ++i) s[i] = o[i];
     }
     if constexpr (STORE) {
-        uint8_t *row = a.out + tile_off(g0, a.pitch_out, a.sh_out, T::S);
+        const __amdgpu_buffer_rsrc_t r = make_srd(a.out + tile_off(g0, a.pitch_out, a.sh_out, T::S));
+        const uint32_t rs = (uint32_t)a.pitch_out;
 #pragma unroll
-        for (int i = 0; i < T::S; ++i) { st<V, NT>(row + lo, s[i]); row += a.pitch_out; }
+        for (int i = 0; i < T::S; ++i) bst<V, P::ST>(r, lo, i * rs, s[i]);
     }
     if (a.done != nullptr || a.reward != nullptr) {
         const Pk<V> dn = done_bytes(unsolved<T, V>(s));
@@ -116,21 +131,22 @@ __device__ __forceinline__ void step_body(const StepArgs &a, int64_t g0, uint32_
     if constexpr (CODE) {
         Pk<V> c[T::SLOTS];
         encode<T, V>(s, c);
-        uint8_t *row = a.code + tile_off(g0, a.code_pitch, a.sh_code, T::SLOTS);
+        const __amdgpu_buffer_rsrc_t r = make_srd(a.code + tile_off(g0, a.code_pitch, a.sh_code, T::SLOTS));
+        const uint32_t rs = (uint32_t)a.code_pitch;
 #pragma unroll
-        for (int p = 0; p < T::SLOTS; ++p) { st<V, NT>(row + lo, c[p]); row += a.code_pitch; }
+        for (int p = 0; p < T::SLOTS; ++p) bst<V, P::ST>(r, lo, p * rs, c[p]);
     }
 }
 
-template <class T, int V, bool MOVE, bool STORE, bool CODE, bool NT, int BLOCK>
+template <class T, int V, bool MOVE, bool STORE, bool CODE, int POL, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_step(StepArgs a) {
     // wave-uniform part of the cube index in SGPRs, 32-bit lane offset in one VGPR
     const int64_t g0 = (int64_t)blockIdx.x * (BLOCK * 4 * V);
     const uint32_t lo = threadIdx.x * (4 * V);
     if (g0 + BLOCK * 4 * V <= a.n) {                           // uniform: the whole workgroup is inside the batch
-        step_body<T, V, MOVE, STORE, CODE, NT, true>(a, g0, lo);
+        step_body<T, V, MOVE, STORE, CODE, POL, true>(a, g0, lo);
     } else if (g0 + lo < a.n) {
-        step_body<T, V, MOVE, STORE, CODE, NT, false>(a, g0, lo);
+        step_body<T, V, MOVE, STORE, CODE, POL, false>(a, g0, lo);
     }
 }
 
@@ -212,52 +228,60 @@ struct ExpandArgs {
     int parts, sh_in, sh_out;
 };
 
-// Row addressing: every row pointer handed to these helpers is WAVE-UNIFORM (kernel argument +
-// block-derived offset, lives in SGPRs); the lane adds a 32-bit offset `lo`.  Keeps the 648
-// child-row addresses of one expansion out of the vector registers.
-__device__ __forceinline__ uint8_t *opaque(uint8_t *p) {
-    // defined inside the loop body on purpose: stops the optimiser from turning every row of
-    // every child into its own loop-carried address register
-    asm volatile("" : "+s"(p));
-    return p;
-}
-
 // Where one expansion's outputs go.  Child a of the wave's cubes: a tiled state buffer of its own,
 // children + a * tiles * S * pitch (layout [A][tile][S][pitch]); codes likewise with SLOTS rows;
 // flags are [A][tiles * pitch].  The three pointers already include the wave's own offset
-// (tile_off / g0), so only the per-child strides are left.
+// (tile_off / g0), so only the per-child strides are left.  Every pointer is WAVE-UNIFORM (kernel
+// argument + block-derived offset, SGPRs): each child gets a buffer descriptor of its own, the rows are
+// scalar offsets, the lane contributes one 32-bit offset -- no address VGPRs at all.
 struct ChildOut {
     uint8_t *children, *child_solved, *child_code;
-    int64_t pitch, tiles;
+    uint32_t pitch;
+    int64_t tiles;
+    bool flags_live;   // REACH only: false = no cube of the wave can have a solved child (wave-uniform), flags are all 0
 };
 
-template <class T, int V, int A_, bool CODE>
-__device__ __forceinline__ void emit_child(const Pk<V> (&s)[T::S], const FamilyCodes<T, V> &fam, const ChildOut &o, uint32_t lo) {
-    Pk<V> c[T::S];
-    fixed_move<T, V, A_>(s, c);
+// REACH: the parent is reachable from the solved cube (ADI walks): flags from the shared ring test
+// (rc_device.h child_unsolved); otherwise the literal per-child face test.
+template <class T, int V, int A_, bool CODE, bool REACH>
+__device__ __forceinline__ void emit_child(const Pk<V> (&s)[T::S], const FamilyCodes<T, V> &fam, const ChildFlags<T, V> &cf,
+                                           const ChildOut &o, uint32_t lo) {
+    const int64_t wp = o.tiles * o.pitch;
     if (o.children) {
-        uint8_t *row = opaque(o.children + (int64_t)A_ * T::S * o.tiles * o.pitch);
-#pragma unroll
-        for (int i = 0; i < T::S; ++i) { st<V, RC_OUT_NT>(row + lo, c[i]); row += o.pitch; }
+        const __amdgpu_buffer_rsrc_t r = make_srd(o.children + (int64_t)A_ * T::S * wp);
+        sfor<T::S>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            bst<V, RC_OUT_AUX>(r, lo, i * o.pitch, s[kPerm<T>.v[A_][i]]);   // the child is a register renaming of the parent
+        });
     }
-    if (o.child_solved) st<V, RC_OUT_NT>(o.child_solved + (int64_t)A_ * o.tiles * o.pitch + lo, done_bytes(unsolved<T, V>(c)));
+    if (o.child_solved) {
+        Pk<V> flag = splat<V>(0);
+        if constexpr (REACH) {
+            if (o.flags_live) flag = done_bytes(child_unsolved<T, V, A_>(s, cf));
+        } else {
+            Pk<V> c[T::S];
+            fixed_move<T, V, A_>(s, c);
+            flag = done_bytes(unsolved<T, V>(c));
+        }
+        bst<V, RC_OUT_AUX>(make_srd(o.child_solved + (int64_t)A_ * wp), lo, 0, flag);
+    }
     if constexpr (CODE) {
         Pk<V> cc[T::SLOTS];
         family_pick<T, V, A_>(fam, cc);
-        uint8_t *row = opaque(o.child_code + (int64_t)A_ * T::SLOTS * o.tiles * o.pitch);
+        const __amdgpu_buffer_rsrc_t r = make_srd(o.child_code + (int64_t)A_ * T::SLOTS * wp);
 #pragma unroll
-        for (int p = 0; p < T::SLOTS; ++p) { st<V, RC_OUT_NT>(row + lo, cc[p]); row += o.pitch; }
+        for (int p = 0; p < T::SLOTS; ++p) bst<V, RC_OUT_AUX>(r, lo, p * o.pitch, cc[p]);
     }
 }
 
-// children part, part+parts, ... of one parent pack; pointers are wave-uniform; `fam` (the family's shared
-// code look-ups) is only read when CODE
-template <class T, int V, bool CODE>
-__device__ __forceinline__ void emit_children(const Pk<V> (&s)[T::S], const FamilyCodes<T, V> &fam, int part, int parts,
-                                              const ChildOut &o, uint32_t lo) {
+// children part, part+parts, ... of one parent pack; `fam` (the family's shared code look-ups) is only
+// read when CODE, `cf` only when REACH
+template <class T, int V, bool CODE, bool REACH>
+__device__ __forceinline__ void emit_children(const Pk<V> (&s)[T::S], const FamilyCodes<T, V> &fam, const ChildFlags<T, V> &cf,
+                                              int part, int parts, const ChildOut &o, uint32_t lo) {
     sfor<T::A>([&](auto ac) {
         constexpr int a = decltype(ac)::value;
-        if ((a - part) % parts == 0 && a >= part) emit_child<T, V, a, CODE>(s, fam, o, lo);
+        if ((a - part) % parts == 0 && a >= part) emit_child<T, V, a, CODE, REACH>(s, fam, cf, o, lo);
     });
 }
 
@@ -271,16 +295,18 @@ __global__ void __launch_bounds__(kWave) k_expand(ExpandArgs a) {
     if (g0 + lo >= a.n) return;
     Pk<V> s[T::S];
     {
-        const uint8_t *row = a.in + tile_off(g0, a.pitch_in, a.sh_in, T::S);
+        const __amdgpu_buffer_rsrc_t r = make_srd(a.in + tile_off(g0, a.pitch_in, a.sh_in, T::S));
+        const uint32_t rs = (uint32_t)a.pitch_in;
 #pragma unroll
-        for (int i = 0; i < T::S; ++i) { s[i] = ld<V, false>(row + lo); row += a.pitch_in; }
+        for (int i = 0; i < T::S; ++i) s[i] = bld<V, kAuxCached>(r, lo, i * rs);
     }
     const ChildOut o{a.children ? a.children + tile_off(g0, a.pitch_out, a.sh_out, T::S) : nullptr,
                      a.child_solved ? a.child_solved + g0 : nullptr,
-                     a.child_code ? a.child_code + tile_off(g0, a.pitch_out, a.sh_out, T::SLOTS) : nullptr, a.pitch_out, a.tiles_out};
+                     a.child_code ? a.child_code + tile_off(g0, a.pitch_out, a.sh_out, T::SLOTS) : nullptr, (uint32_t)a.pitch_out, a.tiles_out, true};
     FamilyCodes<T, V> fam;
+    ChildFlags<T, V> cf;
     if constexpr (CODE) family_codes<T, V>(s, fam);
-    emit_children<T, V, CODE>(s, fam, part, a.parts, o, lo);
+    emit_children<T, V, CODE, false>(s, fam, cf, part, a.parts, o, lo);
 }
 
 // ------------------------------------------------------------------------------- ADI
@@ -295,6 +321,8 @@ struct AdiArgs {
 // One wave = 256*V walks, kept in registers for all `depth` steps (persistent over depth).
 // `parts` waves share a walk group: each recomputes the (cheap) walk and writes its share of
 // the children, which is where all the bytes go; part 0 also writes actions and parents.
+// Large batches run V = 2 (8 walks per lane, 512 B per store instruction) with ONE wave per walk group
+// (pick_geometry; DESIGN.md "ADI write path").
 template <class T, int V, bool CODE>
 __global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
     const int64_t item = blockIdx.x;
@@ -312,10 +340,13 @@ __global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
 #pragma unroll
         for (int j = 0; j < 4 * V; ++j) rng[j].seed(a.seed, a.stream_id, (uint64_t)(a.walk_offset + w0 + j));
     }
+    const int64_t wp = a.tiles * a.pitch;
+    const uint32_t rs = (uint32_t)a.pitch;
+    const int64_t st_off = tile_off(g0, a.pitch, a.shift, T::S), code_off = tile_off(g0, a.pitch, a.shift, T::SLOTS);
     for (int d = 0; d < a.depth; ++d) {
         Pk<V> act;
         if (a.actions_in != nullptr) {
-            act = ld<V, false>(a.actions_in + (int64_t)d * a.tiles * a.pitch + w0);
+            act = bld<V, kAuxCached>(make_srd(a.actions_in + (int64_t)d * wp + g0), lo, 0);
         } else {
 #pragma unroll
             for (int k = 0; k < V; ++k) {
@@ -325,39 +356,50 @@ __global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
                 act.d[k] = x;
             }
         }
-        Pk<V> m[T::A];
-        const Pk<V> bad = action_masks<T, V>(act, m);
-        if (any_bad<V>(bad, w0, a.n_walks)) atomicOr(&g_status, RC_STATUS_BAD_ACTION);
-        Pk<V> o[T::S];
-        apply_move<T, V>(s, m, o);
+        {
+            Pk<V> m[T::A];
+            const Pk<V> bad = action_masks<T, V>(act, m);
+            if (any_bad<V>(bad, w0, a.n_walks)) atomicOr(&g_status, RC_STATUS_BAD_ACTION);
+            Pk<V> o[T::S];
+            apply_move<T, V>(s, m, o);
 #pragma unroll
-        for (int i = 0; i < T::S; ++i) s[i] = o[i];
+            for (int i = 0; i < T::S; ++i) s[i] = o[i];
+        }
         FamilyCodes<T, V> fam;
+        ChildFlags<T, V> cf;
         if constexpr (CODE) family_codes<T, V>(s, fam);
+        // a child can only be solved when its parent is a power of one face turn away from solved, i.e. when every sticker outside
+        // that face's ring is home (not_ring == 0).  After a few random moves no walk of the wave is: skip the 12 ring tests.
+        bool flags_live = false;
+        if (a.child_solved) {
+            child_flags_prepare<T, V>(s, cf);
+            Pk<V> near = splat<V>(0);
+            sfor<T::A / 2>([&](auto fc) { near = near | done_bytes(cf.not_ring[decltype(fc)::value]); });
+            flags_live = __any(any(near));
+        }
         if (part == 0) {
-            if (a.actions_out) st<V, RC_OUT_NT>(a.actions_out + (int64_t)d * a.tiles * a.pitch + w0, act);
+            if (a.actions_out) bst<V, RC_OUT_AUX>(make_srd(a.actions_out + (int64_t)d * wp + g0), lo, 0, act);
             if (a.parents) {
-                uint8_t *row = opaque(a.parents + (int64_t)d * T::S * a.tiles * a.pitch + tile_off(g0, a.pitch, a.shift, T::S));
+                const __amdgpu_buffer_rsrc_t r = make_srd(a.parents + (int64_t)d * T::S * wp + st_off);
 #pragma unroll
-                for (int i = 0; i < T::S; ++i) { st<V, RC_OUT_NT>(row + lo, s[i]); row += a.pitch; }
+                for (int i = 0; i < T::S; ++i) bst<V, RC_OUT_AUX>(r, lo, i * rs, s[i]);
             }
             if constexpr (CODE) {
                 if (a.parent_code) {
                     Pk<V> pc[T::SLOTS];
                     family_pick<T, V, -1>(fam, pc);
-                    uint8_t *row = opaque(a.parent_code + (int64_t)d * T::SLOTS * a.tiles * a.pitch + tile_off(g0, a.pitch, a.shift, T::SLOTS));
+                    const __amdgpu_buffer_rsrc_t r = make_srd(a.parent_code + (int64_t)d * T::SLOTS * wp + code_off);
 #pragma unroll
-                    for (int p = 0; p < T::SLOTS; ++p) { st<V, RC_OUT_NT>(row + lo, pc[p]); row += a.pitch; }
+                    for (int p = 0; p < T::SLOTS; ++p) bst<V, RC_OUT_AUX>(r, lo, p * rs, pc[p]);
                 }
             }
         }
-        const int64_t wp = a.tiles * a.pitch;
-        const ChildOut co{a.children ? a.children + (int64_t)d * T::A * T::S * wp + tile_off(g0, a.pitch, a.shift, T::S) : nullptr,
+        const ChildOut co{a.children ? a.children + (int64_t)d * T::A * T::S * wp + st_off : nullptr,
                          a.child_solved ? a.child_solved + (int64_t)d * T::A * wp + g0 : nullptr,
-                         a.child_code ? a.child_code + (int64_t)d * T::A * T::SLOTS * wp + tile_off(g0, a.pitch, a.shift, T::SLOTS) : nullptr,
-                         a.pitch, a.tiles};
-        if (CODE && co.child_code != nullptr) emit_children<T, V, CODE>(s, fam, part, a.parts, co, lo);
-        else emit_children<T, V, false>(s, fam, part, a.parts, co, lo);
+                         a.child_code ? a.child_code + (int64_t)d * T::A * T::SLOTS * wp + code_off : nullptr,
+                         rs, a.tiles, flags_live};
+        if (CODE && co.child_code != nullptr) emit_children<T, V, CODE, true>(s, fam, cf, part, a.parts, co, lo);
+        else emit_children<T, V, false, true>(s, fam, cf, part, a.parts, co, lo);
     }
 }
 
@@ -442,7 +484,8 @@ __global__ void __launch_bounds__(kWave) k_legacy_actions(const uint32_t *seeds,
     const int lane = threadIdx.x;
     const int64_t env = (int64_t)blockIdx.x * kWave + lane;
     const bool live = env < n;
-    const int want = live ? (counts ? counts[env] : count_uniform) : 0;
+    int want = live ? (counts ? counts[env] : count_uniform) : 0;
+    want = want < 0 ? 0 : want > kmax ? kmax : want;           // counts live in device memory: never write past [kmax][pitch]
     uint32_t x = live ? seeds[env] : 0u;                       // init_genrand
     mt[lane] = x;
     for (int i = 1; i < kMtN; ++i) {
@@ -495,9 +538,75 @@ __global__ void __launch_bounds__(256) k_adi_targets(const float *child_value, c
     if (error) error[i] = fabs((double)parent_value[i] - (double)tv) * weight[i];  // cube_env.py:247-251
 }
 
+// ------------------------------------------------------- batch-1 facade step (latency path)
+// CubeEnv.step for ONE cube (cube_env.py:71-111): the action arrives by value in the launch arguments, the new
+// one-hot (dense uint8, R*C bytes), the done flag and a sequence word are written straight into a
+// HOST-MAPPED pinned buffer, so the caller needs no upload, no download and no stream synchronisation:
+// it polls the sequence word.  One wave; every lane carries the same (single-cube) pack, lane l then
+// writes bytes 8l..8l+7 of the one-hot.  Layout of `host_out` (512 bytes): [0, R*C) one-hot, [496] done,
+// [504..507] sequence (written last, after a system-scope fence).
+constexpr int kFacadeBytes = 512, kFacadeDone = 496, kFacadeSeq = 504;
+
+template <class T>
+__global__ void __launch_bounds__(kWave) k_facade_step(uint8_t *st, uint32_t pitch, uint32_t action, uint8_t *host_out, uint32_t seq) {
+    __shared__ uint8_t code_lds[32];
+    const int lane = threadIdx.x;
+    Pk<1> s[T::S];
+#pragma unroll
+    for (int i = 0; i < T::S; ++i) s[i].d[0] = st[i * pitch];             // cube 0 only; uniform loads
+    Pk<1> act;
+    act.d[0] = action & 0xffu;                                            // bytes 1..3 (pad cubes): action 0
+    Pk<1> m[T::A];
+    const Pk<1> bad = action_masks<T, 1>(act, m);
+    if (bad.d[0] & 0xffu) atomicOr(&g_status, RC_STATUS_BAD_ACTION);
+    Pk<1> o[T::S];
+    apply_move<T, 1>(s, m, o);
+    if (lane < T::S) {
+        // lane i stores sticker i: a run-time register index is avoided by a compile-time select chain
+        uint32_t v = 0;
+        sfor<T::S>([&](auto ic) { constexpr int i = decltype(ic)::value; if (lane == i) v = o[i].d[0]; });
+        st[lane * pitch] = (uint8_t)v;
+    }
+    const Pk<1> dn = done_bytes(unsolved<T, 1>(o));
+    Pk<1> c[T::SLOTS];
+    encode<T, 1>(o, c);
+    if (lane == 0) {
+#pragma unroll
+        for (int p = 0; p < T::SLOTS; ++p) code_lds[p] = (uint8_t)c[p].d[0];
+    }
+    __syncthreads();
+    constexpr int RC_ = T::R * T::C;
+    if (lane * 8 < RC_) {
+        uint32_t w[2] = {0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = lane * 8 + j;
+            if (e < RC_) {
+                const int r = e / T::C, col = e - r * T::C;
+                bool one;
+                if constexpr (T::SIZE == 3) one = code_lds[r] == col;                      // row = slot, column = code
+                else { const int slot = col / 3, ori = col - slot * 3; one = code_lds[slot] == r * 3 + ori; }   // row = piece (cube_env.py:143-147)
+                if (one) w[j >> 2] |= 1u << (8 * (j & 3));
+            }
+        }
+        if (lane * 8 + 8 <= RC_) {
+            u32x2 u = {w[0], w[1]};
+            *reinterpret_cast<u32x2 *>(host_out + lane * 8) = u;
+        } else {
+            for (int j = 0; lane * 8 + j < RC_; ++j) host_out[lane * 8 + j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+        }
+    }
+    if (lane == 0) host_out[kFacadeDone] = (uint8_t)(dn.d[0] & 1u);
+    __threadfence_system();
+    __syncthreads();
+    if (lane == 0) __hip_atomic_store(reinterpret_cast<uint32_t *>(host_out + kFacadeSeq), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// read-and-clear of the status word in one atomic, result into host-mapped memory
+__global__ void k_read_status(uint32_t *host_word) { *host_word = atomicExch(&g_status, 0u); }
+
 // ------------------------------------------------------------------------- host side
 thread_local char t_err[256] = "";
-int g_variant = 0;
 
 int fail(int code, const char *fmt, const char *detail = "") {
     snprintf(t_err, sizeof t_err, fmt, detail);
@@ -513,8 +622,10 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 inline bool bad_pitch(int64_t pitch, int64_t n) { return pitch < n || (pitch & 15) != 0; }  // single-tile buffers
 // state / code buffers may be tiled: one tile (pitch >= n, pitch % 16 == 0) or several
 // (pitch a power of two >= 1024).  Returns the shift for tile_off, or -1 if the pitch is bad.
-inline int tile_shift(int64_t pitch, int64_t n) {
-    if (pitch <= 0 || (pitch & 15) != 0) return -1;
+// Row offsets inside a tile are 32-bit scalar offsets of buffer instructions: rows * pitch < 2^32
+// (a single tile of more than 79 M 3x3x3 cubes has to be split into tiles).
+inline int tile_shift(int64_t pitch, int64_t n, int rows = 54) {
+    if (pitch <= 0 || (pitch & 15) != 0 || pitch * rows >= ((int64_t)1 << 32)) return -1;
     if (n <= pitch) return 63;
     if (pitch < 1024 || (pitch & (pitch - 1)) != 0) return -1;
     int sh = 0;
@@ -522,6 +633,9 @@ inline int tile_shift(int64_t pitch, int64_t n) {
     return sh;
 }
 inline hipStream_t S(void *s) { return static_cast<hipStream_t>(s); }
+inline bool grid_ok(int64_t blocks) { return blocks > 0 && blocks <= 0x7fffffff; }
+#define RC_GRID(blocks) \
+    do { if (!grid_ok(blocks)) return fail(RC_EINVAL, "too many cubes for one launch%s"); } while (0)
 
 template <class F>
 int by_size(int cube_size, F &&f) {
@@ -530,49 +644,59 @@ int by_size(int cube_size, F &&f) {
     return fail(RC_EINVAL, "cube_size must be 2 or 3%s");  // NotImplementedError, cube_env.py:44
 }
 
-// rc_set_variant(v): v % 10 = pack width (1,2,3 -> V = 1,2,4; 0 = auto), (v / 10) % 10 = row
-// traffic policy (1 = non-temporal, 2 = default-cached, 0 = auto).
-// Measured on MI355X at 4M cubes (tools/exp/exp_step.hip): V = 2 (8 cubes per lane, dwordx2 rows)
-// beats V = 1 and V = 4; non-temporal row traffic wins once the working set no longer fits the
-// 256 MiB Infinity Cache and loses when it does (1M cubes).
-int pick_v(int64_t n) {
-    const int v = g_variant % 10;
+// Per-call tuning override of the *_ex entry points (0 = the measured defaults).  Decimal digits:
+//   units      pack width: 1,2,3 -> V = 1,2,4 (4, 8, 16 cubes per lane)
+//   tens       row-traffic policy of the step kernel: 1 -> POL 2 (stream), 2 -> POL 0 (cached), 3 -> POL 1 (keep)
+//   thousands  (2 digits) parts per walk group for expansion / ADI (1..A)
+//   100000s    dense one-hot tile: 1 -> 64, 2 -> 256 cubes per workgroup
+// Measured on MI355X at 4M cubes (tools/exp/exp_step.hip, exp_step2.hip): V = 2 (8 cubes per lane, dwordx2
+// rows) beats V = 1 and V = 4 for the step kernel; the policy follows the working set (RowPolicy).
+int pick_v(int64_t n, int variant) {
+    const int v = variant % 10;
     if (v >= 1 && v <= 3) return v == 1 ? 1 : v == 2 ? 2 : 4;
     return n >= (int64_t)1 << 18 ? 2 : 1;
 }
-bool pick_nt(int64_t touched_bytes) {
-    const int p = (g_variant / 10) % 10;
-    if (p == 1) return true;
-    if (p == 2) return false;
-    return touched_bytes > ((int64_t)240 << 20);  // beyond the Infinity Cache: stream past it
+constexpr int64_t kMallBytes = (int64_t)240 << 20;   // what we count on of the 256 MiB Infinity Cache
+int pick_policy(int64_t in_bytes, int64_t out_bytes, bool in_place, int variant) {
+    const int p = (variant / 10) % 10;
+    if (p == 1) return 2;
+    if (p == 2) return 0;
+    if (p == 3) return 1;
+    const int64_t touched = in_place ? in_bytes : in_bytes + out_bytes;
+    if (touched <= kMallBytes) return 0;               // resident: default-cached (1M cubes run out of the Infinity Cache)
+    if (!in_place && out_bytes > 0 && out_bytes <= kMallBytes) return 1;   // stream the input, keep the output for the next launch
+    return 2;
 }
 
 template <class T, int V, bool MOVE, bool STORE, bool CODE>
-int launch_step(const StepArgs &a, hipStream_t st) {
+int launch_step(const StepArgs &a, hipStream_t st, int variant) {
     constexpr int BLOCK = 64;
     const int64_t lanes = (a.n + 4 * V - 1) / (4 * V);
     const int64_t blocks = (lanes + BLOCK - 1) / BLOCK;
-    if (blocks > 0x7fffffff) return fail(RC_EINVAL, "too many cubes for one launch%s");
-    const bool nt = pick_nt(a.n * T::S * ((STORE && a.out != a.in) ? 2 : 1));
-    if (nt) hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, true, BLOCK>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
-    else hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, false, BLOCK>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
+    RC_GRID(blocks);
+    const bool writes = STORE && a.out != nullptr;
+    const int pol = pick_policy(a.n * T::S, writes ? a.n * T::S : 0, writes && a.out == a.in, variant);
+    const dim3 g((unsigned)blocks), b(BLOCK);
+    if (pol == 2) hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, 2, BLOCK>), g, b, 0, st, a);
+    else if (pol == 1) hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, 1, BLOCK>), g, b, 0, st, a);
+    else hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, 0, BLOCK>), g, b, 0, st, a);
     RC_HIP(hipGetLastError());
     return RC_OK;
 }
 
 template <class T, bool MOVE, bool STORE, bool CODE>
-int dispatch_step(const StepArgs &a, hipStream_t st) {
-    switch (pick_v(a.n)) {
-        case 4: return launch_step<T, 4, MOVE, STORE, CODE>(a, st);
-        case 2: return launch_step<T, 2, MOVE, STORE, CODE>(a, st);
-        default: return launch_step<T, 1, MOVE, STORE, CODE>(a, st);
+int dispatch_step(const StepArgs &a, hipStream_t st, int variant) {
+    switch (pick_v(a.n, variant)) {
+        case 4: return launch_step<T, 4, MOVE, STORE, CODE>(a, st, variant);
+        case 2: return launch_step<T, 2, MOVE, STORE, CODE>(a, st, variant);
+        default: return launch_step<T, 1, MOVE, STORE, CODE>(a, st, variant);
     }
 }
 
 // Measured at 1M cubes (tools/microbench.py densetile): 256-cube tiles 5.4 TB/s (f32) / 6.3 TB/s (u8) against
-// 4.9 / 5.4 with 1024-cube tiles -- shorter private write streams per workgroup (DESIGN.md "ADI write ceiling").
-inline int dense_tile(int64_t n) {
-    const int forced = (g_variant / 100000) % 10;  // rc_set_variant: 100000 / 200000 force 64 / 256
+// 4.9 / 5.4 with 1024-cube tiles -- shorter private write streams per workgroup.
+inline int dense_tile(int64_t n, int variant) {
+    const int forced = (variant / 100000) % 10;
     if (forced) return forced == 1 ? 64 : 256;
     return n >= ((int64_t)1 << 17) ? 256 : 64;
 }
@@ -580,7 +704,7 @@ inline int dense_tile(int64_t n) {
 template <class T, bool MOVE, bool STORE, int TILE>
 int launch_dense_t(const StepArgs &a, void *onehot, int fmt, hipStream_t st) {
     const int64_t blocks = (a.n + TILE - 1) / TILE;
-    if (blocks > 0x7fffffff) return fail(RC_EINVAL, "too many cubes for one launch%s");
+    RC_GRID(blocks);
     const dim3 g((unsigned)blocks), b(kDenseBlock);
     if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_step_dense<T, uint8_t, MOVE, STORE, TILE>), g, b, 0, st, a, static_cast<uint8_t *>(onehot));
     else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_step_dense<T, uint16_t, MOVE, STORE, TILE>), g, b, 0, st, a, static_cast<uint16_t *>(onehot));
@@ -591,8 +715,8 @@ int launch_dense_t(const StepArgs &a, void *onehot, int fmt, hipStream_t st) {
 }
 
 template <class T, bool MOVE, bool STORE>
-int launch_dense(const StepArgs &a, void *onehot, int fmt, hipStream_t st) {
-    switch (dense_tile(a.n)) {
+int launch_dense(const StepArgs &a, void *onehot, int fmt, hipStream_t st, int variant) {
+    switch (dense_tile(a.n, variant)) {
         case 256: return launch_dense_t<T, MOVE, STORE, 256>(a, onehot, fmt, st);
         default: return launch_dense_t<T, MOVE, STORE, 64>(a, onehot, fmt, st);
     }
@@ -600,7 +724,9 @@ int launch_dense(const StepArgs &a, void *onehot, int fmt, hipStream_t st) {
 
 template <class T, int TILE>
 int launch_code_to_dense(const uint8_t *code, int64_t n, int64_t code_pitch, int sh, void *onehot, int fmt, hipStream_t st) {
-    const dim3 g((unsigned)((n + TILE - 1) / TILE)), b(kDenseBlock);
+    const int64_t blocks = (n + TILE - 1) / TILE;
+    RC_GRID(blocks);
+    const dim3 g((unsigned)blocks), b(kDenseBlock);
     if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_code_to_dense<T, uint8_t, TILE>), g, b, 0, st, code, n, code_pitch, sh, static_cast<uint8_t *>(onehot));
     else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_code_to_dense<T, uint16_t, TILE>), g, b, 0, st, code, n, code_pitch, sh, static_cast<uint16_t *>(onehot));
     else if (fmt == RC_FMT_BF16) hipLaunchKernelGGL((k_code_to_dense<T, Bf16, TILE>), g, b, 0, st, code, n, code_pitch, sh, static_cast<Bf16 *>(onehot));
@@ -614,19 +740,51 @@ int check_fmt(void *onehot, int fmt, int64_t code_pitch, int64_t n, int *sh_code
     if ((fmt == RC_FMT_NONE) != (onehot == nullptr)) return fail(RC_EINVAL, "onehot pointer and fmt disagree%s");
     if (onehot && !aligned16(onehot)) return fail(RC_EINVAL, "onehot must be 16-byte aligned%s");
     *sh_code = 63;
-    if (fmt == RC_FMT_CODE && (*sh_code = tile_shift(code_pitch, n)) < 0) return fail(RC_EINVAL, "code_pitch: need pitch %% 16 == 0 and pitch >= n_cubes, or a power-of-two tile >= 1024%s");
+    if (fmt == RC_FMT_CODE && (*sh_code = tile_shift(code_pitch, n, 20)) < 0) return fail(RC_EINVAL, "code_pitch: need pitch %% 16 == 0 and pitch >= n_cubes, or a power-of-two tile >= 1024%s");
     return RC_OK;
 }
 
-int parts_for(int64_t groups, int A, int64_t want = 2048) {
-    // enough wave-items to cover 256 CUs a few times over; parts must divide A (1,2,3,4,6,12 | 1,2,3,6).
-    // rc_set_variant: (v / 1000) % 100 forces the value (benchmarks).
-    const int forced = (g_variant / 1000) % 100;
+// Expansion / ADI launch geometry (measured on MI355X, profiles/r02_design_ab.json).  A large write-once output
+// stream is fastest with FEW waves issuing WIDE stores: 100k walks x 30 run 0.32 ms with 196 waves of 8 walks per lane
+// against 0.41-0.43 ms with 2346 waves of 4 walks per lane; 16 walks per lane would be better still for the stores alone
+// (7.2 TB/s in the store-only harness) but one wave per 1024 walks cannot hide the walk's VALU work (0.44 ms).  Small
+// batches are latency-bound instead: spread them over the chip.  Code-only expansion is VALU-bound: narrow packs.
+struct Geometry { int v, parts; };
+Geometry pick_geometry(int64_t n, int A, int variant, bool stickers_out, int64_t out_bytes) {
+    const int fv = variant % 10, fp = (variant / 1000) % 100;
+    const bool stream = stickers_out && out_bytes >= ((int64_t)256 << 20);
+    const int64_t want = stream ? 96 : stickers_out ? 2048 : 700;
+    int v = 1;
+    if (fv == 1 || fv == 2) v = fv;
+    else if (stream && n >= want * kWave * 8) v = 2;
+    const int64_t groups = (n + kWave * 4 * v - 1) / (kWave * 4 * v);
     int parts = 1;
-    if (forced >= 1 && forced <= A) parts = forced;
+    if (fp >= 1 && fp <= A) parts = fp;
     else while (parts < A && groups * parts < want) ++parts;
     while (A % parts) ++parts;
-    return parts;
+    return {v, parts};
+}
+
+template <class T, int V>
+int launch_expand(ExpandArgs a, hipStream_t st) {
+    const int64_t groups = (a.n + kWave * 4 * V - 1) / (kWave * 4 * V);
+    RC_GRID(groups * a.parts);
+    const dim3 g((unsigned)(groups * a.parts)), b(kWave);
+    if (a.child_code) hipLaunchKernelGGL((k_expand<T, V, true>), g, b, 0, st, a);
+    else hipLaunchKernelGGL((k_expand<T, V, false>), g, b, 0, st, a);
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
+template <class T, int V>
+int launch_adi(AdiArgs a, hipStream_t st) {
+    const int64_t groups = (a.n_walks + kWave * 4 * V - 1) / (kWave * 4 * V);
+    RC_GRID(groups * a.parts);
+    const dim3 g((unsigned)(groups * a.parts)), b(kWave);
+    if (a.parent_code || a.child_code) hipLaunchKernelGGL((k_adi<T, V, true>), g, b, 0, st, a);
+    else hipLaunchKernelGGL((k_adi<T, V, false>), g, b, 0, st, a);
+    RC_HIP(hipGetLastError());
+    return RC_OK;
 }
 
 }  // namespace
@@ -634,14 +792,9 @@ int parts_for(int64_t groups, int A, int64_t want = 2048) {
 // =============================================================================== C ABI
 extern "C" {
 
-int rc_version(void) { return 100; }
+int rc_version(void) { return 200; }
 
 const char *rc_last_error(void) { return t_err; }
-
-int rc_set_variant(int variant) {
-    g_variant = variant;
-    return RC_OK;
-}
 
 int rc_init(int device) {
     int count = 0, prev = 0;
@@ -682,6 +835,7 @@ int rc_fill_solved(uint8_t *stp, int64_t n, int64_t pitch, int cube_size, void *
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
         const int64_t blocks = (n + kWave * 16 - 1) / (kWave * 16);
+        RC_GRID(blocks);
         hipLaunchKernelGGL((k_fill_solved<T>), dim3((unsigned)blocks), dim3(kWave), 0, S(stream), stp, n, pitch, sh);
         RC_HIP(hipGetLastError());
         return RC_OK;
@@ -690,7 +844,7 @@ int rc_fill_solved(uint8_t *stp, int64_t n, int64_t pitch, int cube_size, void *
 
 static int step_common(const uint8_t *in, uint8_t *out, const uint8_t *actions, int64_t n, int64_t pitch_in, int64_t pitch_out,
                        int cube_size, float *reward, uint8_t *done, void *onehot, int fmt, int64_t code_pitch, void *stream,
-                       bool move, bool store) {
+                       bool move, bool store, int variant) {
     const int sh_in = tile_shift(pitch_in, n), sh_out = store ? tile_shift(pitch_out, n) : 63;
     int sh_code = 63;
     if (!in || !aligned16(in) || n < 0 || sh_in < 0) return fail(RC_EINVAL, "bad input state buffer / pitch%s");
@@ -705,21 +859,26 @@ static int step_common(const uint8_t *in, uint8_t *out, const uint8_t *actions, 
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
         if (fmt >= RC_FMT_U8) {
-            if (move) return launch_dense<T, true, true>(a, onehot, fmt, st);
-            return launch_dense<T, false, false>(a, onehot, fmt, st);
+            if (move) return launch_dense<T, true, true>(a, onehot, fmt, st, variant);
+            return launch_dense<T, false, false>(a, onehot, fmt, st, variant);
         }
         if (move) {
-            if (fmt == RC_FMT_CODE) return dispatch_step<T, true, true, true>(a, st);
-            return dispatch_step<T, true, true, false>(a, st);
+            if (fmt == RC_FMT_CODE) return dispatch_step<T, true, true, true>(a, st, variant);
+            return dispatch_step<T, true, true, false>(a, st, variant);
         }
-        if (fmt == RC_FMT_CODE) return dispatch_step<T, false, false, true>(a, st);
-        return dispatch_step<T, false, false, false>(a, st);
+        if (fmt == RC_FMT_CODE) return dispatch_step<T, false, false, true>(a, st, variant);
+        return dispatch_step<T, false, false, false>(a, st, variant);
     });
+}
+
+int rc_apply_moves_ex(const uint8_t *in, uint8_t *out, const uint8_t *actions, int64_t n, int64_t pitch_in, int64_t pitch_out,
+                      int cube_size, float *reward, uint8_t *done, void *onehot, int fmt, int64_t code_pitch, void *stream, int variant) {
+    return step_common(in, out, actions, n, pitch_in, pitch_out, cube_size, reward, done, onehot, fmt, code_pitch, stream, true, true, variant);
 }
 
 int rc_apply_moves(const uint8_t *in, uint8_t *out, const uint8_t *actions, int64_t n, int64_t pitch_in, int64_t pitch_out,
                    int cube_size, float *reward, uint8_t *done, void *onehot, int fmt, int64_t code_pitch, void *stream) {
-    return step_common(in, out, actions, n, pitch_in, pitch_out, cube_size, reward, done, onehot, fmt, code_pitch, stream, true, true);
+    return step_common(in, out, actions, n, pitch_in, pitch_out, cube_size, reward, done, onehot, fmt, code_pitch, stream, true, true, 0);
 }
 
 int rc_scramble(uint8_t *stp, int64_t n, int64_t pitch, int cube_size, int depth, uint64_t seed, uint64_t stream_id,
@@ -734,8 +893,9 @@ int rc_scramble(uint8_t *stp, int64_t n, int64_t pitch, int cube_size, int depth
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
         ScrambleArgs a{stp, n, pitch, depth, sh, seed, stream_id, walk_offset, actions_in, actions_out, act_pitch, done, reward};
-        const dim3 g((unsigned)((n + kWave * 4 - 1) / (kWave * 4))), b(kWave);
-        hipLaunchKernelGGL((k_scramble<T>), g, b, 0, S(stream), a);
+        const int64_t blocks = (n + kWave * 4 - 1) / (kWave * 4);
+        RC_GRID(blocks);
+        hipLaunchKernelGGL((k_scramble<T>), dim3((unsigned)blocks), dim3(kWave), 0, S(stream), a);
         RC_HIP(hipGetLastError());
         return RC_OK;
     });
@@ -746,7 +906,9 @@ int rc_legacy_scramble_actions(const uint32_t *seeds, const int32_t *counts, int
     if (!seeds || !actions_out || n < 0 || kmax < 0 || bad_pitch(pitch, n)) return fail(RC_EINVAL, "rc_legacy_scramble_actions: bad arguments%s");
     if (!counts && (count_uniform < 0 || count_uniform > kmax)) return fail(RC_EINVAL, "rc_legacy_scramble_actions: count_uniform must be in 0..kmax%s");
     if (n == 0 || kmax == 0) return RC_OK;
-    const dim3 g((unsigned)((n + kWave - 1) / kWave)), b(kWave);
+    const int64_t blocks = (n + kWave - 1) / kWave;
+    RC_GRID(blocks);
+    const dim3 g((unsigned)blocks), b(kWave);
     if (cube_size == 3) hipLaunchKernelGGL((k_legacy_actions<12>), g, b, 0, S(stream), seeds, counts, count_uniform, kmax, n, actions_out, pitch);
     else if (cube_size == 2) hipLaunchKernelGGL((k_legacy_actions<6>), g, b, 0, S(stream), seeds, counts, count_uniform, kmax, n, actions_out, pitch);
     else return fail(RC_EINVAL, "cube_size must be 2 or 3%s");
@@ -756,30 +918,30 @@ int rc_legacy_scramble_actions(const uint32_t *seeds, const int32_t *counts, int
 
 int rc_is_solved(const uint8_t *stp, int64_t n, int64_t pitch, int cube_size, uint8_t *done, float *reward, void *stream) {
     if (!done && !reward) return fail(RC_EINVAL, "rc_is_solved: nothing to write%s");
-    return step_common(stp, nullptr, nullptr, n, pitch, 0, cube_size, reward, done, nullptr, RC_FMT_NONE, 0, stream, false, false);
+    return step_common(stp, nullptr, nullptr, n, pitch, 0, cube_size, reward, done, nullptr, RC_FMT_NONE, 0, stream, false, false, 0);
 }
 
 int rc_encode(const uint8_t *stp, int64_t n, int64_t pitch, int cube_size, void *onehot, int fmt, int64_t code_pitch, void *stream) {
     if (fmt == RC_FMT_NONE) return fail(RC_EINVAL, "rc_encode: fmt must not be RC_FMT_NONE%s");
-    return step_common(stp, nullptr, nullptr, n, pitch, 0, cube_size, nullptr, nullptr, onehot, fmt, code_pitch, stream, false, false);
+    return step_common(stp, nullptr, nullptr, n, pitch, 0, cube_size, nullptr, nullptr, onehot, fmt, code_pitch, stream, false, false, 0);
 }
 
 int rc_onehot_from_code(const uint8_t *code, int64_t n, int64_t code_pitch, int cube_size, void *onehot, int fmt, void *stream) {
-    const int sh = tile_shift(code_pitch, n);
+    const int sh = tile_shift(code_pitch, n, 20);
     if (!code || !aligned16(code) || n < 0 || sh < 0) return fail(RC_EINVAL, "bad code buffer / pitch%s");
     if (fmt < RC_FMT_U8 || fmt > RC_FMT_BF16 || !onehot || !aligned16(onehot)) return fail(RC_EINVAL, "rc_onehot_from_code: dense fmt and aligned buffer required%s");
     if (n == 0) return RC_OK;
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
-        switch (dense_tile(n)) {
+        switch (dense_tile(n, 0)) {
             case 256: return launch_code_to_dense<T, 256>(code, n, code_pitch, sh, onehot, fmt, S(stream));
             default: return launch_code_to_dense<T, 64>(code, n, code_pitch, sh, onehot, fmt, S(stream));
         }
     });
 }
 
-int rc_expand_children(const uint8_t *in, int64_t n, int64_t pitch_in, int cube_size, uint8_t *children, uint8_t *child_solved,
-                       uint8_t *child_code, int64_t pitch_out, void *stream) {
+int rc_expand_children_ex(const uint8_t *in, int64_t n, int64_t pitch_in, int cube_size, uint8_t *children, uint8_t *child_solved,
+                          uint8_t *child_code, int64_t pitch_out, void *stream, int variant) {
     const int sh_in = tile_shift(pitch_in, n), sh_out = tile_shift(pitch_out, n);
     if (!in || !aligned16(in) || n < 0 || sh_in < 0 || sh_out < 0) return fail(RC_EINVAL, "rc_expand_children: bad buffer / pitch%s");
     if (!children && !child_solved && !child_code) return fail(RC_EINVAL, "rc_expand_children: nothing to write%s");
@@ -788,27 +950,22 @@ int rc_expand_children(const uint8_t *in, int64_t n, int64_t pitch_in, int cube_
     if (n == 0) return RC_OK;
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
-        const int V = n >= ((int64_t)1 << 20) ? 2 : 1;
-        const int64_t groups = (n + kWave * 4 * V - 1) / (kWave * 4 * V);
+        const Geometry geo = pick_geometry(n, T::A, variant, children != nullptr, n * T::S * T::A);
         ExpandArgs a{in, n, pitch_in, children, child_solved, child_code, pitch_out, n <= pitch_out ? 1 : (n + pitch_out - 1) / pitch_out,
-                     parts_for(groups, T::A), sh_in, sh_out};
-        const dim3 g((unsigned)(groups * a.parts)), b(kWave);
+                     geo.parts, sh_in, sh_out};
         hipStream_t st = S(stream);
-        if (V == 2) {
-            if (child_code) hipLaunchKernelGGL((k_expand<T, 2, true>), g, b, 0, st, a);
-            else hipLaunchKernelGGL((k_expand<T, 2, false>), g, b, 0, st, a);
-        } else {
-            if (child_code) hipLaunchKernelGGL((k_expand<T, 1, true>), g, b, 0, st, a);
-            else hipLaunchKernelGGL((k_expand<T, 1, false>), g, b, 0, st, a);
-        }
-        RC_HIP(hipGetLastError());
-        return RC_OK;
+        return geo.v == 2 ? launch_expand<T, 2>(a, st) : launch_expand<T, 1>(a, st);
     });
 }
 
-int rc_adi_generate(uint64_t seed, uint64_t stream_id, int64_t walk_offset, int64_t n_walks, int depth, int cube_size, int64_t pitch,
-                    const uint8_t *actions_in, uint8_t *actions_out, uint8_t *parents, uint8_t *parent_code, uint8_t *children,
-                    uint8_t *child_code, uint8_t *child_solved, void *stream) {
+int rc_expand_children(const uint8_t *in, int64_t n, int64_t pitch_in, int cube_size, uint8_t *children, uint8_t *child_solved,
+                       uint8_t *child_code, int64_t pitch_out, void *stream) {
+    return rc_expand_children_ex(in, n, pitch_in, cube_size, children, child_solved, child_code, pitch_out, stream, 0);
+}
+
+int rc_adi_generate_ex(uint64_t seed, uint64_t stream_id, int64_t walk_offset, int64_t n_walks, int depth, int cube_size, int64_t pitch,
+                       const uint8_t *actions_in, uint8_t *actions_out, uint8_t *parents, uint8_t *parent_code, uint8_t *children,
+                       uint8_t *child_code, uint8_t *child_solved, void *stream, int variant) {
     const int sh = tile_shift(pitch, n_walks);
     if (n_walks < 0 || depth < 0 || sh < 0) return fail(RC_EINVAL, "rc_adi_generate: bad sizes / pitch%s");
     const void *ptrs[] = {actions_in, actions_out, parents, parent_code, children, child_code, child_solved};
@@ -817,19 +974,21 @@ int rc_adi_generate(uint64_t seed, uint64_t stream_id, int64_t walk_offset, int6
     if (n_walks == 0 || depth == 0) return RC_OK;
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
-        const int V = 1;
-        const int64_t groups = (n_walks + kWave * 4 * V - 1) / (kWave * 4 * V);
         const bool any_child = children || child_code || child_solved;
-        // sticker children are byte-bound: split them over many waves; code-only expansion is VALU-bound
-        // (every part re-encodes the parent), measured best at 2 parts for 100k walks
+        Geometry geo = pick_geometry(n_walks, T::A, variant, children != nullptr, n_walks * depth * T::S * T::A);
+        if (!any_child && (variant / 1000) % 100 == 0) geo.parts = 1;
         AdiArgs a{seed, stream_id, walk_offset, n_walks, pitch, n_walks <= pitch ? 1 : (n_walks + pitch - 1) / pitch, depth,
-                  any_child ? parts_for(groups, T::A, children ? 2048 : 700) : 1, sh, actions_in, actions_out, parents, parent_code, children, child_code, child_solved};
-        const dim3 g((unsigned)(groups * a.parts)), b(kWave);
-        if (parent_code || child_code) hipLaunchKernelGGL((k_adi<T, 1, true>), g, b, 0, S(stream), a);
-        else hipLaunchKernelGGL((k_adi<T, 1, false>), g, b, 0, S(stream), a);
-        RC_HIP(hipGetLastError());
-        return RC_OK;
+                  geo.parts, sh, actions_in, actions_out, parents, parent_code, children, child_code, child_solved};
+        hipStream_t st = S(stream);
+        return geo.v == 2 ? launch_adi<T, 2>(a, st) : launch_adi<T, 1>(a, st);
     });
+}
+
+int rc_adi_generate(uint64_t seed, uint64_t stream_id, int64_t walk_offset, int64_t n_walks, int depth, int cube_size, int64_t pitch,
+                    const uint8_t *actions_in, uint8_t *actions_out, uint8_t *parents, uint8_t *parent_code, uint8_t *children,
+                    uint8_t *child_code, uint8_t *child_solved, void *stream) {
+    return rc_adi_generate_ex(seed, stream_id, walk_offset, n_walks, depth, cube_size, pitch, actions_in, actions_out, parents, parent_code,
+                              children, child_code, child_solved, stream, 0);
 }
 
 int rc_adi_targets(const float *child_value, const uint8_t *child_solved, const float *parent_value, const double *weight, int64_t n,
@@ -837,7 +996,9 @@ int rc_adi_targets(const float *child_value, const uint8_t *child_solved, const 
     if (!child_value || !child_solved || !target_value || !target_policy || n < 0 || pitch < n) return fail(RC_EINVAL, "rc_adi_targets: bad arguments%s");
     if (error && (!parent_value || !weight)) return fail(RC_EINVAL, "rc_adi_targets: error needs parent_value and weight%s");
     if (n == 0) return RC_OK;
-    const dim3 g((unsigned)((n + 255) / 256)), b(256);
+    const int64_t blocks = (n + 255) / 256;
+    RC_GRID(blocks);
+    const dim3 g((unsigned)blocks), b(256);
     if (cube_size == 3) hipLaunchKernelGGL((k_adi_targets<12>), g, b, 0, S(stream), child_value, child_solved, parent_value, weight, n, pitch, target_value, target_policy, error);
     else if (cube_size == 2) hipLaunchKernelGGL((k_adi_targets<6>), g, b, 0, S(stream), child_value, child_solved, parent_value, weight, n, pitch, target_value, target_policy, error);
     else return fail(RC_EINVAL, "cube_size must be 2 or 3%s");
@@ -845,12 +1006,40 @@ int rc_adi_targets(const float *child_value, const uint8_t *child_solved, const 
     return RC_OK;
 }
 
+int rc_facade_step(uint8_t *stp, int64_t pitch, int cube_size, int action, uint8_t *host_out, uint32_t seq, int wait, void *stream) {
+    if (!stp || !host_out || pitch <= 0 || pitch * 54 >= ((int64_t)1 << 32)) return fail(RC_EINVAL, "rc_facade_step: bad arguments%s");
+    if (action < 0 || action > 255) return fail(RC_EINVAL, "rc_facade_step: action out of the byte range%s");
+    if (seq == 0) return fail(RC_EINVAL, "rc_facade_step: seq must be non-zero%s");
+    const int rc = by_size(cube_size, [&](auto t) {
+        using T = decltype(t);
+        hipLaunchKernelGGL((k_facade_step<T>), dim3(1), dim3(kWave), 0, S(stream), stp, (uint32_t)pitch, (uint32_t)action, host_out, seq);
+        RC_HIP(hipGetLastError());
+        return RC_OK;
+    });
+    if (rc != RC_OK || !wait) return rc;
+    // poll the sequence word the kernel writes last; fall back to a stream sync if it does not show up (e.g. host_out is not
+    // host-visible memory), so a wrong buffer becomes an error instead of a hang
+    volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(host_out + kFacadeSeq);
+    for (int spin = 0; spin < 20000000; ++spin) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return RC_OK;
+        __builtin_ia32_pause();
+    }
+    RC_HIP(hipStreamSynchronize(S(stream)));
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return RC_OK;
+    return fail(RC_EHIP, "rc_facade_step: the result never reached host_out (is it host-mapped pinned memory?)%s");
+}
+
 int rc_read_status(uint32_t *status, void *stream) {
     if (!status) return fail(RC_EINVAL, "status is NULL%s");
-    uint32_t zero = 0;
+    // one atomic read-and-clear on the device (bits set by kernels still running on OTHER streams are neither lost nor
+    // reported early: they show in a later read); the word travels through a pinned, host-mapped scratch word
+    static thread_local uint32_t *host_word = nullptr;
+    if (!host_word) RC_HIP(hipHostMalloc(reinterpret_cast<void **>(&host_word), sizeof(uint32_t), hipHostMallocMapped));
+    *host_word = 0xffffffffu;
+    hipLaunchKernelGGL(k_read_status, dim3(1), dim3(1), 0, S(stream), host_word);
+    RC_HIP(hipGetLastError());
     RC_HIP(hipStreamSynchronize(S(stream)));
-    RC_HIP(hipMemcpyFromSymbol(status, HIP_SYMBOL(g_status), sizeof *status));
-    if (*status) RC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_status), &zero, sizeof zero));
+    *status = *host_word;
     return RC_OK;
 }
 

@@ -122,8 +122,9 @@ def _onehot_args(onehot, fmt, n, cube_size, what):
     return onehot, 0
 
 
-def apply_moves(src, dst, actions, n, cube_size, reward=None, done=None, onehot=None, fmt=FMT_NONE):
-    """CubeEnv.step for n cubes (cube_env.py:71-111).  dst may be src (in place)."""
+def apply_moves(src, dst, actions, n, cube_size, reward=None, done=None, onehot=None, fmt=FMT_NONE, variant=0):
+    """CubeEnv.step for n cubes (cube_env.py:71-111).  dst may be src (in place).
+    variant: per-call tuning override (include/rubikhip.h "Tuning override"; tests and benchmarks only)."""
     S, _, _ = _size(cube_size)
     p_in, p_out = _tiled(src, S, n, "apply_moves src"), _tiled(dst, S, n, "apply_moves dst")
     _vec(actions, n, torch.uint8, "actions")
@@ -131,6 +132,10 @@ def apply_moves(src, dst, actions, n, cube_size, reward=None, done=None, onehot=
     _vec(done, n, torch.uint8, "done")
     oh, cp = _onehot_args(onehot, fmt, n, cube_size, "apply_moves")
     _lib.init(src.device)
+    if variant:
+        check(lib().rc_apply_moves_ex(ptr(src), ptr(dst), ptr(actions), n, p_in, p_out, cube_size, ptr(reward), ptr(done),
+                                      ptr(oh), fmt, cp, stream_ptr(src.device), variant))
+        return
     check(lib().rc_apply_moves(ptr(src), ptr(dst), ptr(actions), n, p_in, p_out, cube_size, ptr(reward), ptr(done),
                                ptr(oh), fmt, cp, stream_ptr(src.device)))
 
@@ -241,7 +246,7 @@ def expand_buffers(n, cube_size, device, pitch=None, children=False, codes=True)
     return out
 
 
-def expand_children(st, n, cube_size, children=None, child_solved=None, child_code=None, pitch=None):
+def expand_children(st, n, cube_size, children=None, child_solved=None, child_code=None, pitch=None, variant=0):
     """All A children of every cube (cube_env.py:212-236, mcts.py:96-101).  Outputs share one tiling:
     children [A, tiles, S, pitch], child_code [A, tiles, SLOTS, pitch], child_solved [A, tiles * pitch]
     (tile axis optional when tiles == 1).  `pitch` defaults to the last dim of the first output given."""
@@ -264,11 +269,11 @@ def expand_children(st, n, cube_size, children=None, child_solved=None, child_co
     if children is None and child_solved is None and child_code is None:
         raise RubikHipError("expand_children: nothing to write")
     _lib.init(st.device)
-    check(lib().rc_expand_children(ptr(st), n, p_in, cube_size, ptr(children), ptr(child_solved), ptr(child_code),
-                                   pitch, stream_ptr(st.device)))
+    check(lib().rc_expand_children_ex(ptr(st), n, p_in, cube_size, ptr(children), ptr(child_solved), ptr(child_code),
+                                      pitch, stream_ptr(st.device), variant))
 
 
-ADI_TILE = 4096
+ADI_TILE = 16384   # walks per output tile: measured best for the ADI kernel's output stream (profiles/r02_design_ab.json)
 
 
 def adi_buffers(n_walks, depth, cube_size, device, pitch=None, actions=True, parents=False, parent_code=False,
@@ -296,7 +301,7 @@ def adi_buffers(n_walks, depth, cube_size, device, pitch=None, actions=True, par
 
 
 def adi_generate(n_walks, depth, cube_size, pitch, device, seed=0, stream_id=0, walk_offset=0, actions_in=None,
-                 actions_out=None, parents=None, parent_code=None, children=None, child_code=None, child_solved=None):
+                 actions_out=None, parents=None, parent_code=None, children=None, child_code=None, child_solved=None, variant=0):
     """ADI walks + expansion (cube_env.py:177-194,212-236); layouts in include/rubikhip.h / adi_buffers."""
     S, A, SL = _size(cube_size)
     tiles = _tiles_of(n_walks, pitch)
@@ -309,9 +314,9 @@ def adi_generate(n_walks, depth, cube_size, pitch, device, seed=0, stream_id=0, 
     _out(child_solved, (depth, A), tiles, 0, pitch, "child_solved")
     dev = torch.device(device)
     _lib.init(dev)
-    check(lib().rc_adi_generate(seed, stream_id, walk_offset, n_walks, depth, cube_size, pitch, ptr(actions_in),
-                                ptr(actions_out), ptr(parents), ptr(parent_code), ptr(children), ptr(child_code),
-                                ptr(child_solved), stream_ptr(dev)))
+    check(lib().rc_adi_generate_ex(seed, stream_id, walk_offset, n_walks, depth, cube_size, pitch, ptr(actions_in),
+                                   ptr(actions_out), ptr(parents), ptr(parent_code), ptr(children), ptr(child_code),
+                                   ptr(child_solved), stream_ptr(dev), variant))
 
 
 def adi_targets(child_value, child_solved, n, cube_size, parent_value=None, weight=None):

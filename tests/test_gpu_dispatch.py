@@ -1,0 +1,202 @@
+"""Every launch geometry the host code can choose is executed and compared with the CPU oracle.  GPU only.
+
+Round-1 review: the default dispatch only ever took `parts = 12` and pack width 1 in the tests, so the instantiations
+that run at BASELINE sizes (wide packs, few parts, 16384-walk tiles) were never compared.  Here:
+  * rc_expand_children_ex / rc_adi_generate_ex force parts in {1,2,3,4,6,12} ({1,2,3,6} for 2x2x2) x pack width
+    {1,2} and compare every output with the oracle;
+  * the default dispatch runs at its real sizes: expansion of 2^20 (+3, ragged) parents, BASELINE config 3
+    (100 000 walks x depth 30) in full, and rc_apply_moves at 1M and 4M cubes on ALL cubes.
+Reference lines restated by the oracle: gym-cube/gym_cube/envs/cube_env.py:177-194,212-236 (ADI / children),
+assets/py333.py:220-246 (move, solved, one-hot)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+S_OF = {2: 24, 3: 54}
+A_OF = {2: 6, 3: 12}
+SL_OF = {2: 7, 3: 20}
+PARTS = {3: (1, 2, 3, 4, 6, 12), 2: (1, 2, 3, 6)}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from rubiks_cube_solver_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def L():
+    from rubiks_cube_solver_amd import _lib
+    return _lib
+
+
+def untile(ops, t, n, lead):
+    """[*lead, tiles, rows, pitch] (or [*lead, rows, pitch]) -> numpy [*lead, n, rows]."""
+    if t.dim() == lead + 2:
+        t = t.unsqueeze(lead)
+    flat = t.reshape(-1, *t.shape[lead:])
+    out = torch.stack([ops.to_aos(x, n) for x in flat]).reshape(*t.shape[:lead], n, t.shape[-2])
+    return out.cpu().numpy()
+
+
+def walk_states(oracle, cs, n, depth, seed, threads=8):
+    """n random states, `depth` oracle moves from solved (host memory stays at a few state arrays)."""
+    rng = np.random.default_rng(seed)
+    st = oracle.solved(cs, n)
+    for _ in range(depth):
+        st = oracle.step(cs, st, rng.integers(0, A_OF[cs], n, dtype=np.uint8), threads=threads)[0]
+    return st
+
+
+@pytest.mark.parametrize("cs", [3, 2])
+@pytest.mark.parametrize("v", [1, 2])
+@pytest.mark.parametrize("n,pitch", [(2500, None), (9000, 1024), (9000, 4096)])
+def test_expand_every_parts_value(ops, L, oracle, cs, v, n, pitch):
+    S, A, SL = S_OF[cs], A_OF[cs], SL_OF[cs]
+    states = walk_states(oracle, cs, n, 20, seed=n + v)
+    k = n // 9
+    states[:k] = oracle.step(cs, oracle.solved(cs, k), np.arange(k) % A)[0]        # parents with a solved child
+    ch, cc, cso = oracle.expand(cs, states, threads=8)
+    src = ops.from_aos(states, "cuda")
+    for parts in PARTS[cs]:
+        out = ops.expand_buffers(n, cs, "cuda", pitch or L.pitch_for(n), children=True, codes=True)
+        for t in out.values():
+            t.fill_(9)
+        ops.expand_children(src, n, cs, out["children"], out["child_solved"], out["child_code"], pitch=out["children"].shape[-1],
+                            variant=parts * 1000 + v)
+        assert (untile(ops, out["children"], n, 1).transpose(1, 0, 2) == ch).all(), parts
+        assert (untile(ops, out["child_code"], n, 1).transpose(1, 0, 2) == cc).all(), parts
+        assert (out["child_solved"][:, :n].cpu().numpy().T == cso).all() and cso.any(), parts
+    assert L.read_status() == 0
+
+
+@pytest.mark.parametrize("cs", [3, 2])
+@pytest.mark.parametrize("v", [1, 2])
+@pytest.mark.parametrize("n_walks,depth,pitch", [(1500, 6, None), (5000, 5, 1024), (5000, 5, 2048)])
+def test_adi_every_parts_value(ops, L, oracle, cs, v, n_walks, depth, pitch):
+    exp = oracle.adi(cs, n_walks, depth, seed=77, stream=2, walk0=5, threads=8)
+    for parts in PARTS[cs]:
+        pt, bufs = ops.adi_buffers(n_walks, depth, cs, "cuda", pitch or L.pitch_for(n_walks), parents=True, parent_code=True,
+                                   children=True, child_code=True)
+        for t in bufs.values():
+            t.fill_(7)
+        ops.adi_generate(n_walks, depth, cs, pt, "cuda", seed=77, stream_id=2, walk_offset=5, variant=parts * 1000 + v, **bufs)
+        assert (bufs["actions_out"][:, :n_walks].cpu().numpy().T == exp["actions"]).all(), parts
+        assert (untile(ops, bufs["parents"], n_walks, 1).transpose(1, 0, 2) == exp["parents"]).all(), parts
+        assert (untile(ops, bufs["parent_code"], n_walks, 1).transpose(1, 0, 2) == exp["parent_code"]).all(), parts
+        assert (untile(ops, bufs["children"], n_walks, 2).transpose(2, 0, 1, 3) == exp["children"]).all(), parts
+        assert (untile(ops, bufs["child_code"], n_walks, 2).transpose(2, 0, 1, 3) == exp["child_code"]).all(), parts
+        assert (bufs["child_solved"][..., :n_walks].cpu().numpy().transpose(2, 0, 1) == exp["child_solved"]).all(), parts
+        assert exp["child_solved"].any()
+        # stickers only (the byte-bound instantiation without code look-ups)
+        pt, b2 = ops.adi_buffers(n_walks, depth, cs, "cuda", pitch or L.pitch_for(n_walks), parents=True, children=True)
+        ops.adi_generate(n_walks, depth, cs, pt, "cuda", seed=77, stream_id=2, walk_offset=5, variant=parts * 1000 + v, **b2)
+        assert torch.equal(b2["children"], bufs["children"]) or \
+            (untile(ops, b2["children"], n_walks, 2).transpose(2, 0, 1, 3) == exp["children"]).all()
+        assert (b2["child_solved"][..., :n_walks].cpu().numpy().transpose(2, 0, 1) == exp["child_solved"]).all(), parts
+    assert L.read_status() == 0
+
+
+@pytest.mark.parametrize("n", [(1 << 20) + 3])
+@pytest.mark.parametrize("codes", [False, True])
+def test_expand_one_million_parents_default_dispatch(ops, L, oracle, n, codes):
+    """The instantiation the MCTS / ADI callers get at scale (wide pack, one part, 32768-cube tiles): all children of
+    2^20 + 3 parents against the oracle (cube_env.py:212-236)."""
+    cs, A = 3, 12
+    states = walk_states(oracle, cs, n, 14, seed=3, threads=oracle.max_threads())
+    states[:1000] = oracle.step(cs, oracle.solved(cs, 1000), np.arange(1000) % A)[0]
+    ch, cc, cso = oracle.expand(cs, states, threads=oracle.max_threads())
+    src = ops.from_aos(states, "cuda")
+    out = ops.expand_buffers(n, cs, "cuda", children=True, codes=codes)
+    ops.expand_children(src, n, cs, out["children"], out["child_solved"], out.get("child_code"), pitch=out["children"].shape[-1])
+    assert out["children"].shape[1] > 1                                           # tiled
+    assert (out["child_solved"][:, :n].cpu().numpy().T == cso).all() and cso.sum() >= 1000
+    for a in range(A):                                                            # child by child: keeps host memory bounded
+        assert (ops.to_aos(out["children"][a], n).cpu().numpy() == ch[:, a]).all(), a
+        if codes:
+            assert (ops.to_aos(out["child_code"][a], n).cpu().numpy() == cc[:, a]).all(), a
+    assert L.read_status() == 0
+
+
+def test_adi_config3_full_size(ops, L, oracle):
+    """BASELINE config 3 exactly as bench.py launches it: 100 000 walks x depth 30 from solved, default dispatch and
+    default tiling, every output byte against the oracle (streamed in walk chunks): actions, parents, all 12 children
+    and their solved flags (cube_env.py:177-194,212-236)."""
+    cs, W, D, A, S = 3, 100_000, 30, 12, 54
+    pt, bufs = ops.adi_buffers(W, D, cs, "cuda", parents=True, children=True)
+    assert bufs["children"].shape[2] > 1                                          # the tiled layout bench.py uses
+    ops.adi_generate(W, D, cs, pt, "cuda", seed=2024, stream_id=0, **bufs)
+    assert L.read_status() == 0
+    chunk = pt                                                                    # one output tile of walks at a time
+    n_solved = 0
+    for w0 in range(0, W, chunk):
+        m = min(chunk, W - w0)
+        exp = oracle.adi(cs, m, D, seed=2024, stream=0, walk0=w0, threads=oracle.max_threads())
+        t = w0 // pt
+        assert (bufs["actions_out"][:, w0:w0 + m].cpu().numpy().T == exp["actions"]).all(), w0
+        par = bufs["parents"][:, t, :, :m].cpu().numpy()                          # [D, S, m]
+        assert (par.transpose(2, 0, 1) == exp["parents"]).all(), w0
+        kids = bufs["children"][:, :, t, :, :m].cpu().numpy()                     # [D, A, S, m]
+        assert (kids.transpose(3, 0, 1, 2) == exp["children"]).all(), w0
+        flags = bufs["child_solved"][:, :, w0:w0 + m].cpu().numpy()               # [D, A, m]
+        assert (flags.transpose(2, 0, 1) == exp["child_solved"]).all(), w0
+        n_solved += int(exp["child_solved"].sum())
+    assert n_solved >= W                                                          # depth 1: the inverse move solves every walk
+
+
+@pytest.mark.parametrize("log2n", [20, 22])
+def test_apply_moves_full_batch_vs_oracle(ops, L, oracle, log2n):
+    """BASELINE config 2 (2^20 cubes) and the metric's batch (2^22): one rc_apply_moves launch with reward, done and the
+    compact code, default dispatch, compared with the oracle on ALL cubes (SURVEY 8d asks for >= 64 K)."""
+    cs, n = 3, 1 << log2n
+    thr = oracle.max_threads()
+    states = walk_states(oracle, cs, n, 20, seed=log2n, threads=thr)
+    acts = np.random.default_rng(log2n).integers(0, 12, n, dtype=np.uint8)
+    k = 4096
+    states[:k] = oracle.step(cs, oracle.solved(cs, k), (acts[:k] ^ 1))[0]         # these become solved again
+    exp_st, exp_code, exp_done, exp_rew = oracle.step(cs, states, acts, threads=thr)
+    src = ops.from_aos(states, "cuda")
+    dst = torch.empty_like(src)
+    a_d = torch.from_numpy(acts).cuda()
+    rew = torch.empty(n, dtype=torch.float32, device="cuda")
+    done = torch.empty(n, dtype=torch.uint8, device="cuda")
+    code = ops.alloc_code(n, cs, "cuda")
+    ops.apply_moves(src, dst, a_d, n, cs, rew, done, code, L.FMT_CODE)
+    assert src.shape[0] > 1
+    assert (ops.to_aos(dst, n).cpu().numpy() == exp_st).all()
+    assert (ops.to_aos(code, n).cpu().numpy() == exp_code).all()
+    assert (done.cpu().numpy() == exp_done).all() and exp_done[:k].all()
+    assert (rew.cpu().numpy() == exp_rew).all()
+    # the bench's launch shape: move + done only, and in place
+    done2 = torch.empty_like(done)
+    dst2 = torch.empty_like(src)
+    ops.apply_moves(src, dst2, a_d, n, cs, None, done2)
+    assert torch.equal(dst2, dst) and torch.equal(done2, done)
+    ops.apply_moves(src, src, a_d, n, cs, None, done2)
+    assert torch.equal(src, dst) and torch.equal(done2, done)
+    assert L.read_status() == 0
+
+
+@pytest.mark.parametrize("cs", [3, 2])
+def test_step_policies_agree_at_scale(ops, L, cs):
+    """The three row-traffic policies and both pack widths of the step kernel produce identical bytes on a batch large
+    enough to take the full-wave fast path everywhere (2^21 + 5 cubes, ragged tail)."""
+    n = (1 << 21) + 5
+    A = A_OF[cs]
+    st = ops.alloc_states(n, cs, "cuda")
+    ops.fill_solved(st, n, cs)
+    ops.scramble(st, n, cs, 15, seed=cs)
+    acts = torch.randint(0, A, (n,), dtype=torch.uint8, device="cuda")
+    ref = torch.empty_like(st)
+    ref_done = torch.empty(n, dtype=torch.uint8, device="cuda")
+    ops.apply_moves(st, ref, acts, n, cs, None, ref_done, variant=21)              # narrow pack, default-cached
+    valid = ops.to_aos(ref, n)
+    for variant in (0, 11, 12, 22, 31, 32, 13, 23, 33):
+        out = torch.zeros_like(st)
+        done = torch.zeros_like(ref_done)
+        ops.apply_moves(st, out, acts, n, cs, None, done, variant=variant)
+        assert torch.equal(ops.to_aos(out, n), valid), variant
+        assert torch.equal(done, ref_done), variant
+    assert L.read_status() == 0

@@ -106,43 +106,39 @@ def test_fill_and_is_solved(ops, oracle, cs, n, pitch):
 
 
 @pytest.mark.parametrize("cs", CS)
-@pytest.mark.parametrize("variant", [1, 2, 3, 11, 12, 23])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 11, 12, 23, 31, 32])   # pack width x row-traffic policy (per-call override)
 @pytest.mark.parametrize("n,pitch", [(1, None), (5, None), (64, 64), (255, None), (1021, None), (16384 + 3, None),
                                      (16384 + 3, 1024), (16384 + 3, 32768)])
 def test_apply_moves_vs_oracle(ops, L, oracle, cs, variant, n, pitch):
-    L.lib().rc_set_variant(variant)
-    try:
-        S, A = S_OF[cs], A_OF[cs]
-        states = random_states(oracle, cs, n, 17, seed=n + cs)
-        rng = np.random.default_rng(n * 7 + cs)
-        acts = rng.integers(0, A, n, dtype=np.uint8)
-        # make some cubes one move from solved so done/reward see both values
-        k = max(1, n // 5)
-        states[:k] = oracle.solved(cs, k)
-        exp_st, exp_code, exp_done, exp_rew = oracle.step(cs, states, acts)
-        back = np.array([a ^ 1 for a in acts[:k]], np.uint8)
-        src = to_dev(states, pitch)
-        dst = torch.zeros_like(src)
-        a_d = torch.from_numpy(acts).cuda()
-        rew = torch.zeros(n, dtype=torch.float32, device="cuda")
-        done = torch.full((n,), 7, dtype=torch.uint8, device="cuda")
-        code = code_buf(ops, n, cs, src)
-        ops.apply_moves(src, dst, a_d, n, cs, rew, done, code, L.FMT_CODE)
-        assert (st_host(dst, n) == exp_st).all()
-        assert (st_host(code, n) == exp_code).all()
-        assert (done.cpu().numpy() == exp_done).all()
-        assert (rew.cpu().numpy() == exp_rew).all()
-        # second step in place undoes the first k cubes -> solved
-        acts2 = acts.copy()
-        acts2[:k] = back
-        exp2, _, exp_done2, exp_rew2 = oracle.step(cs, exp_st, acts2)
-        ops.apply_moves(dst, dst, torch.from_numpy(acts2).cuda(), n, cs, rew, done)
-        assert (st_host(dst, n) == exp2).all()
-        assert (done.cpu().numpy() == exp_done2).all() and exp_done2[:k].all()
-        assert (rew.cpu().numpy() == exp_rew2).all()
-        assert L.read_status() == 0
-    finally:
-        L.lib().rc_set_variant(0)
+    S, A = S_OF[cs], A_OF[cs]
+    states = random_states(oracle, cs, n, 17, seed=n + cs)
+    rng = np.random.default_rng(n * 7 + cs)
+    acts = rng.integers(0, A, n, dtype=np.uint8)
+    # make some cubes one move from solved so done/reward see both values
+    k = max(1, n // 5)
+    states[:k] = oracle.solved(cs, k)
+    exp_st, exp_code, exp_done, exp_rew = oracle.step(cs, states, acts)
+    back = np.array([a ^ 1 for a in acts[:k]], np.uint8)
+    src = to_dev(states, pitch)
+    dst = torch.zeros_like(src)
+    a_d = torch.from_numpy(acts).cuda()
+    rew = torch.zeros(n, dtype=torch.float32, device="cuda")
+    done = torch.full((n,), 7, dtype=torch.uint8, device="cuda")
+    code = code_buf(ops, n, cs, src)
+    ops.apply_moves(src, dst, a_d, n, cs, rew, done, code, L.FMT_CODE, variant=variant)
+    assert (st_host(dst, n) == exp_st).all()
+    assert (st_host(code, n) == exp_code).all()
+    assert (done.cpu().numpy() == exp_done).all()
+    assert (rew.cpu().numpy() == exp_rew).all()
+    # second step in place undoes the first k cubes -> solved
+    acts2 = acts.copy()
+    acts2[:k] = back
+    exp2, _, exp_done2, exp_rew2 = oracle.step(cs, exp_st, acts2)
+    ops.apply_moves(dst, dst, torch.from_numpy(acts2).cuda(), n, cs, rew, done, variant=variant)
+    assert (st_host(dst, n) == exp2).all()
+    assert (done.cpu().numpy() == exp_done2).all() and exp_done2[:k].all()
+    assert (rew.cpu().numpy() == exp_rew2).all()
+    assert L.read_status() == 0
 
 
 @pytest.mark.parametrize("cs", CS)

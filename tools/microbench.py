@@ -40,35 +40,31 @@ def main():
         t = timeit(lambda: b.copy_(a))
         out.append(dict(k="torch_copy_54rows", ms=t * 1e3, GBps=2 * a.numel() / t / 1e9))
     if "step" in which:
-        for var in (1, 2, 3, 11, 12, 13, 21, 22):
-            L.rc_set_variant(var)
+        for var in (0, 1, 2, 3, 12, 22, 32, 13):
             buf = [a, b]
             def f():
-                ops.apply_moves(buf[0], buf[1], acts, n, 3, None, done)
+                ops.apply_moves(buf[0], buf[1], acts, n, 3, None, done, variant=var)
                 buf.reverse()
             t = timeit(f)
             out.append(dict(k=f"step_v{var}", ms=t * 1e3, Gsteps=n / t / 1e9, GBps=110 * n / t / 1e9))
             def f2():
-                ops.apply_moves(buf[0], buf[1], acts, n, 3, rew, done)
+                ops.apply_moves(buf[0], buf[1], acts, n, 3, rew, done, variant=var)
                 buf.reverse()
             t = timeit(f2)
             out.append(dict(k=f"step_reward_v{var}", ms=t * 1e3, Gsteps=n / t / 1e9, GBps=114 * n / t / 1e9))
             def f3():
-                ops.apply_moves(a, a, acts, n, 3, None, done)
+                ops.apply_moves(a, a, acts, n, 3, None, done, variant=var)
             t = timeit(f3)
             out.append(dict(k=f"step_inplace_v{var}", ms=t * 1e3, Gsteps=n / t / 1e9, GBps=110 * n / t / 1e9))
-        L.rc_set_variant(0)
     if "code" in which:
         code = ops.alloc_code(n, 3, "cuda")
-        for var in (1, 2, 3):
-            L.rc_set_variant(var)
+        for var in (0, 1, 2, 3):
             buf = [a, b]
             def f():
-                ops.apply_moves(buf[0], buf[1], acts, n, 3, None, done, code, _lib.FMT_CODE)
+                ops.apply_moves(buf[0], buf[1], acts, n, 3, None, done, code, _lib.FMT_CODE, variant=var)
                 buf.reverse()
             t = timeit(f)
             out.append(dict(k=f"step_code_v{var}", ms=t * 1e3, Gsteps=n / t / 1e9, GBps=130 * n / t / 1e9))
-        L.rc_set_variant(0)
     if "densetile" in which:
         m = 1 << 20
         oh = torch.empty((m, 20, 24), dtype=torch.float32, device="cuda")
@@ -76,15 +72,13 @@ def main():
         code = ops.alloc_code(m, 3, "cuda")
         ops.encode(a, m, 3, code, _lib.FMT_CODE)
         for rep in range(2):
-            for forced, name in ((100000, 64), (200000, 256), (300000, 1024)):
-                L.rc_set_variant(forced)
-                t = timeit(lambda: ops.apply_moves(a, b, acts, m, 3, None, done, oh, _lib.FMT_F32), iters=10)
+            for forced, name in ((100000, 64), (200000, 256)):
+                t = timeit(lambda: ops.apply_moves(a, b, acts, m, 3, None, done, oh, _lib.FMT_F32, variant=forced), iters=10)
                 out.append(dict(k=f"step_dense_f32_1M_tile{name}", ms=t * 1e3, GBps=(110 + 1920) * m / t / 1e9))
-                t = timeit(lambda: ops.apply_moves(a, b, acts, m, 3, None, done, oh8, _lib.FMT_U8), iters=10)
+                t = timeit(lambda: ops.apply_moves(a, b, acts, m, 3, None, done, oh8, _lib.FMT_U8, variant=forced), iters=10)
                 out.append(dict(k=f"step_dense_u8_1M_tile{name}", ms=t * 1e3, GBps=(110 + 480) * m / t / 1e9))
                 t = timeit(lambda: ops.onehot_from_code(code, m, 3, oh), iters=10)
                 out.append(dict(k=f"code_to_dense_f32_1M_tile{name}", ms=t * 1e3, GBps=(20 + 1920) * m / t / 1e9))
-        L.rc_set_variant(0)
     if "dense" in which:
         m = 1 << 20
         for fmt, name, bpc in ((_lib.FMT_U8, "u8", 480), (_lib.FMT_F16, "f16", 960), (_lib.FMT_F32, "f32", 1920)):
@@ -94,7 +88,7 @@ def main():
             del oh
     if "adi" in which:
         W, D = 100_000, 30
-        for pitch in (None, 4096):
+        for pitch in (None, ops.ADI_TILE):
             tag = "plain" if pitch is None else f"tile{pitch}"
             pt, bufs = ops.adi_buffers(W, D, 3, "cuda", pitch or _lib.pitch_for(W), parents=True, children=True)
             t = timeit(lambda: ops.adi_generate(W, D, 3, pt, "cuda", seed=2024, **bufs), iters=5, warm=2)
@@ -137,19 +131,43 @@ def main():
             pcie_step()
         dt = (time.perf_counter() - t0) / 20
         out.append(dict(k="vec_1M_step_pcie_inclusive(actions H2D, done+code D2H)", ms=dt * 1e3, Gsteps=m / dt / 1e9))
-    if "adiparts" in which:
+    if "adigeo" in which:
+        # launch geometry of the ADI kernel: pack width (units digit 1,2,3 -> 4,8,16 walks per lane) x parts x output tile
         W, D = 100_000, 30
-        for parts in (1, 2, 3, 4, 6, 12):
-            L.rc_set_variant(parts * 1000)
-            pt, bufs = ops.adi_buffers(W, D, 3, "cuda", parents=True, parent_code=True, child_code=True)
+        for pitch in (4096, 8192, 16384, 32768):
+            pt, bufs = ops.adi_buffers(W, D, 3, "cuda", pitch, parents=True, children=True)
+            for v in (1, 2):
+                for parts in (1, 2, 3, 6, 12):
+                    var = parts * 1000 + v
+                    t = timeit(lambda: ops.adi_generate(W, D, 3, pt, "cuda", seed=2024, variant=var, **bufs), iters=5, warm=2)
+                    out.append(dict(k=f"adi_stickers_pitch{pitch}_V{v}_parts{parts}", ms=t * 1e3, Gunits=W * D / t / 1e9, GBps=715 * W * D / t / 1e9))
             t = timeit(lambda: ops.adi_generate(W, D, 3, pt, "cuda", seed=2024, **bufs), iters=5, warm=2)
-            out.append(dict(k=f"adi_codes_parts{parts}", ms=t * 1e3, Gunits=W * D / t / 1e9))
+            out.append(dict(k=f"adi_stickers_pitch{pitch}_default", ms=t * 1e3, Gunits=W * D / t / 1e9, GBps=715 * W * D / t / 1e9))
             del bufs
-            pt, bufs = ops.adi_buffers(W, D, 3, "cuda", parents=True, children=True)
-            t = timeit(lambda: ops.adi_generate(W, D, 3, pt, "cuda", seed=2024, **bufs), iters=5, warm=2)
-            out.append(dict(k=f"adi_stickers_parts{parts}", ms=t * 1e3, Gunits=W * D / t / 1e9, GBps=715 * W * D / t / 1e9))
-            del bufs
-        L.rc_set_variant(0)
+        pt, bufs = ops.adi_buffers(W, D, 3, "cuda", parents=True, parent_code=True, child_code=True)
+        for v in (1, 2):
+            for parts in (1, 2, 3, 6, 12):
+                var = parts * 1000 + v
+                t = timeit(lambda: ops.adi_generate(W, D, 3, pt, "cuda", seed=2024, variant=var, **bufs), iters=5, warm=2)
+                out.append(dict(k=f"adi_codes_V{v}_parts{parts}", ms=t * 1e3, Gunits=W * D / t / 1e9))
+        t = timeit(lambda: ops.adi_generate(W, D, 3, pt, "cuda", seed=2024, **bufs), iters=5, warm=2)
+        out.append(dict(k="adi_codes_default", ms=t * 1e3, Gunits=W * D / t / 1e9))
+        del bufs
+    if "expandgeo" in which:
+        m = 1 << 20
+        src = ops.alloc_states(m, 3, "cuda")
+        ops.fill_solved(src, m, 3)
+        ops.scramble(src, m, 3, 20, seed=5)
+        for pitch in (4096, 8192, 16384, 32768):
+            o = ops.expand_buffers(m, 3, "cuda", pitch, children=True, codes=False)
+            for v in (1, 2):
+                for parts in (1, 2, 6):
+                    var = parts * 1000 + v
+                    t = timeit(lambda: ops.expand_children(src, m, 3, o["children"], o["child_solved"], pitch=pitch, variant=var), iters=20)
+                    out.append(dict(k=f"expand_1M_pitch{pitch}_V{v}_parts{parts}", us=t * 1e6, GBps=(54 + 12 * 54 + 12) * m / t / 1e9))
+            t = timeit(lambda: ops.expand_children(src, m, 3, o["children"], o["child_solved"], pitch=pitch), iters=20)
+            out.append(dict(k=f"expand_1M_pitch{pitch}_default", us=t * 1e6, GBps=(54 + 12 * 54 + 12) * m / t / 1e9))
+            del o
     if "expand" in which:
         for m in (4096, 1 << 20):
             src = ops.alloc_states(m, 3, "cuda")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: cube-move steps/s, 3x3x3, batch 4M per GPU (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu] [--extras]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu] [--no-configs]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -11,6 +11,13 @@ HBM-resident state buffers (working set 453 MB > the 256 MB Infinity Cache, so H
 Inputs are resident in HBM before the timed region.  value = cubes * K * N / max-over-ranks time.
 Every rank owns its own batch and RNG stream (stream_id = rank); there is no collective on the
 env path ("scaling": "weak").  One JSON line is printed by rank 0.
+
+At N = 1 the line also carries "configs": the other BASELINE.json workloads, each timed OUTSIDE the headline's timed
+region with HIP events on the launch stream and with a roofline sub-record of its own (kernel name, algorithmic
+bytes per launch, achieved GB/s, fraction of the 8 TB/s HBM peak): config 2 (1M cubes, move + reward + done), the
+step with the fused compact code and with the fused dense one-hot (f32 / bf16), config 3 (ADI 100k walks x 30,
+715 B per (walk, depth)), the 1M-parent expansion, config 5 (us per MCTS step, eager and as a hipGraph) and the
+batch-1 facade latency.  --no-configs skips them.
 """
 import argparse
 import json
@@ -25,6 +32,27 @@ N_CUBES = 1 << 22
 CUBE = 3
 BYTES_PER_STEP = 54 + 54 + 1 + 1  # stickers R + W, action, done flag
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_share():
+    """Cores this job may use: the smaller of its CPU affinity and its cgroup CPU quota; a one-GPU box of this pool hands a job
+    16 cores without pinning it (affinity still lists every host thread), so without a visible quota that figure is used."""
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(int(q) / int(period)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, q // period)
+        except Exception:
+            pass
+    share = min(affinity, quota) if quota else min(affinity, int(os.environ.get("RC_CPU_SHARE", "16")))
+    return share, affinity, quota
 
 
 def _numpy_env_worker(seconds):
@@ -44,7 +72,7 @@ def _numpy_env_worker(seconds):
 def numpy_env_all_cores(seconds=1.5, procs=None):
     import multiprocessing as mp
     # the GPU box gives a one-GPU job a CPU share of 16 cores: size the pool to that, not to the host's 256 threads
-    procs = procs or min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    procs = procs or cpu_share()[0]
     # the workers are plain CPU processes: do not let a profiler's preload (rocprofv3 sets LD_PRELOAD) make each of
     # them open the GPU
     saved = {k: os.environ.pop(k) for k in list(os.environ) if k == "LD_PRELOAD" or k.startswith(("ROCP", "ROCPROF"))}
@@ -62,13 +90,15 @@ def cpu_baseline(budget_s=8.0):
     from oracle.oracle_np import Oracle, OracleCubeEnv
 
     orc = Oracle()
+    share, affinity, quota = cpu_share()
+    omp_threads = max(1, min(orc.max_threads(), share))          # the cores this job may use, not the host's thread count
     n = 1 << 20
     rng = np.random.default_rng(1)
     walk = rng.integers(0, 12, (n, 1), dtype=np.uint8)
-    states = orc.adi(CUBE, n, 1, actions_in=walk, want_children=False, threads=orc.max_threads())["parents"][:, 0]
+    states = orc.adi(CUBE, n, 1, actions_in=walk, want_children=False, threads=omp_threads)["parents"][:, 0]
     acts = rng.integers(0, 12, n, dtype=np.uint8)
     res = {}
-    for label, threads in (("single", 1), ("all", orc.max_threads())):
+    for label, threads in (("single", 1), ("all", omp_threads)):
         t1 = orc.time_steps(CUBE, states, acts, 1, False, threads)
         iters = max(1, min(2000, int(budget_s / max(t1, 1e-4))))
         t = orc.time_steps(CUBE, states, acts, iters, False, threads)
@@ -88,8 +118,9 @@ def cpu_baseline(budget_s=8.0):
         np_all, np_procs = None, 0
     return {
         "value": res["all"]["steps_per_s"], "unit": "steps/s", "cores": res["all"]["threads"], "kind": "port",
-        "sample": f"C oracle (oracle/rc_oracle.c, OpenMP) step = move+solved flag on 2^20 cubes x {res['all']['iters']} passes "
-                  f"({res['all']['seconds']:.1f} s); host has {os.cpu_count()} logical cores",
+        "affinity_cores": affinity, "cgroup_cpu_quota": quota, "cpu_share_used": share, "host_logical_cores": os.cpu_count(),
+        "sample": f"C oracle (oracle/rc_oracle.c, OpenMP, {res['all']['threads']} threads = this job's CPU share) step = move+solved flag "
+                  f"on 2^20 cubes x {res['all']['iters']} passes ({res['all']['seconds']:.1f} s)",
         "single_core_steps_per_s": res["single"]["steps_per_s"],
         "numpy_env_1core_steps_per_s": np_rate,
         "numpy_env_allcores_steps_per_s": np_all, "numpy_env_processes": np_procs,
@@ -97,13 +128,115 @@ def cpu_baseline(budget_s=8.0):
     }
 
 
+def other_configs(torch, ops, _lib, dev, acts):
+    """BASELINE.json configs 2, 3, 5 and the fused-output variants, each with its own roofline sub-record.
+    Timed with HIP events on the launch stream, outside the headline's timed region."""
+    recs = []
+
+    def timed(fn, iters, warm=5):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        for _ in range(iters):
+            fn()
+        s1.record()
+        torch.cuda.synchronize()
+        return s0.elapsed_time(s1) / iters * 1e-3
+
+    def rec(name, kernel, units, unit_name, bytes_per_unit, t, note=None, bound="hbm"):
+        achieved = bytes_per_unit * units / t / 1e9
+        r = {"config": name, "kernel": kernel, "launch_us": t * 1e6, "value": units / t, "unit": f"{unit_name}/s",
+             "roofline": {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                          "algorithmic_bytes_per_launch": bytes_per_unit * units, "bytes_per_unit": bytes_per_unit}}
+        if note:
+            r["note"] = note
+        recs.append(r)
+
+    m = 1 << 20
+    rew = torch.empty(N_CUBES, dtype=torch.float32, device=dev)
+    done = torch.empty(N_CUBES, dtype=torch.uint8, device=dev)
+    # config 2: batch 1M, single apply_move + reward (+ done) -- the 113 MB ping-pong working set sits in the Infinity Cache
+    a1, b1 = ops.alloc_states(m, CUBE, dev), ops.alloc_states(m, CUBE, dev)
+    ops.fill_solved(a1, m, CUBE)
+    ops.scramble(a1, m, CUBE, 20, seed=1234)
+    pp = [a1, b1]
+    t = timed(lambda: (ops.apply_moves(pp[0], pp[1], acts, m, CUBE, rew, done), pp.reverse()), 200)
+    rec("config 2: 3x3x3 batch 1M, apply_move + reward + done", "k_step<Cube3,2,move,store>", m, "steps", 114, t,
+        "working set 113 MB: served from the 256 MB Infinity Cache, not HBM")
+    # the metric's batch with the reward and with the fused compact one-hot code
+    n = N_CUBES
+    a4, b4 = ops.alloc_states(n, CUBE, dev), ops.alloc_states(n, CUBE, dev)
+    ops.fill_solved(a4, n, CUBE)
+    ops.scramble(a4, n, CUBE, 20, seed=1234)
+    p4 = [a4, b4]
+    t = timed(lambda: (ops.apply_moves(p4[0], p4[1], acts, n, CUBE, rew, done), p4.reverse()), 50)
+    rec("3x3x3 batch 4M, apply_move + reward + done", "k_step<Cube3,2,move,store>", n, "steps", 114, t)
+    code = ops.alloc_code(n, CUBE, dev)
+    t = timed(lambda: (ops.apply_moves(p4[0], p4[1], acts, n, CUBE, rew, done, code, _lib.FMT_CODE), p4.reverse()), 50)
+    rec("3x3x3 batch 4M, apply_move + reward + done + fused compact one-hot code (20 B)", "k_step<Cube3,2,move,store,code>", n, "steps", 134, t)
+    del code, a4, b4, p4
+    # fused dense one-hot in the layout model.py consumes
+    for dt, fmt, name, bpc in ((torch.float32, _lib.FMT_F32, "f32", 1920), (torch.bfloat16, _lib.FMT_BF16, "bf16", 960)):
+        oh = torch.empty((m, 20, 24), dtype=dt, device=dev)
+        t = timed(lambda: ops.apply_moves(a1, b1, acts, m, CUBE, rew, done, oh, fmt), 10, 2)
+        rec(f"3x3x3 batch 1M, apply_move + reward + done + fused dense {name} one-hot [N,20,24]", f"k_step_dense<Cube3,{name},256>", m, "steps",
+            114 + bpc, t)
+        del oh
+    # 1M-parent expansion (the MCTS / ADI child loop at scale)
+    ex = ops.expand_buffers(m, CUBE, dev, children=True, codes=False)
+    t = timed(lambda: ops.expand_children(a1, m, CUBE, ex["children"], ex["child_solved"], pitch=ex["children"].shape[-1]), 30)
+    rec("3x3x3 expansion of 1M parents to all 12 children + solved flags", "k_expand<Cube3,2>", m, "parents", 54 + 12 * 54 + 12, t)
+    del ex, a1, b1, pp
+    # config 3: ADI data generation
+    W, D = 100_000, 30
+    pt, ab = ops.adi_buffers(W, D, CUBE, dev, parents=True, children=True)
+    t = timed(lambda: ops.adi_generate(W, D, CUBE, pt, dev, seed=2024, **ab), 10, 3)
+    rec("config 3: ADI 100k walks x depth 30, parents + 12 children + flags + actions", "k_adi<Cube3,2>", W * D, "walk-depths", 715, t,
+        f"{13 * W * D / t:.4g} cube-move steps/s; output tiles of {pt} walks; 0 bytes read")
+    del ab
+    pt, ab = ops.adi_buffers(W, D, CUBE, dev, parents=True, parent_code=True, child_code=True)
+    t = timed(lambda: ops.adi_generate(W, D, CUBE, pt, dev, seed=2024, **ab), 10, 3)
+    rec("ADI 100k x 30 with compact codes instead of child stickers", "k_adi<Cube3,1,code>", W * D, "walk-depths", 54 + 1 + 12 + 13 * 20, t,
+        "VALU-bound (13 x 20 code look-ups per unit), not a bandwidth figure", bound="valu")
+    del ab
+    torch.cuda.empty_cache()
+    out = {"records": recs}
+    try:                                                           # config 5 (latency-bound: microseconds, not GB/s)
+        from tools.bench_cfg5 import run as cfg5
+        r5 = cfg5(short=True)
+        out["config5_mcts_4096_leaves"] = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in r5.items()}
+    except Exception as e:
+        out["config5_mcts_4096_leaves"] = {"error": str(e)[:200]}
+    try:                                                           # batch-1 facade (the reference-shaped CubeEnv.step)
+        import numpy as np
+        import rubiks_cube_solver_amd as rc
+        env = rc.make_env(torch.device("cpu"), CUBE)
+        env.reset(seed=1, scramble_count=20)
+        seq = np.random.default_rng(0).integers(0, 12, 6000)
+        for a_ in seq[:500]:
+            env.step(int(a_))
+        t0 = time.perf_counter()
+        for a_ in seq[500:]:
+            env.step(int(a_))
+        dt = (time.perf_counter() - t0) / (len(seq) - 500)
+        out["facade_batch1"] = {"CubeEnv.step_us": dt * 1e6, "steps_per_s": 1 / dt,
+                                "note": "reference: 24.6 us/step on one CPU core (SURVEY.md section 6); rc_facade_step, results via host-mapped memory"}
+    except Exception as e:
+        out["facade_batch1"] = {"error": str(e)[:200]}
+    return out
+
+
 def main():
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before anything initialises the HIP runtime (RCCL / IPC, N > 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--extras", action="store_true", help="also time fused reward / code / ADI variants (outside the timed region)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs (timed outside the headline region)")
+    ap.add_argument("--extras", action="store_true", help="(kept for compatibility: the configs are on by default)")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
 
@@ -121,7 +254,6 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # reporting only (barrier + MAX of elapsed time): the env path itself has no collective
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -167,52 +299,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dev_ms = float(t[0]), float(t[1])
 
-    extras = {}
-    if args.extras and rank == 0:
-        def timed(fn, iters=50):
-            for _ in range(5):
-                fn()
-            torch.cuda.synchronize()
-            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s0.record()
-            for _ in range(iters):
-                fn()
-            s1.record()
-            torch.cuda.synchronize()
-            return s0.elapsed_time(s1) / iters * 1e-3
-        rew = torch.empty(n, dtype=torch.float32, device=dev)
-        code = ops.alloc_code(n, CUBE, dev)
-        t = timed(lambda: (ops.apply_moves(bufs[0], bufs[1], acts, n, CUBE, rew, done), bufs.reverse()))
-        extras["step_reward_done"] = {"steps_per_s": n / t, "GBps": 114 * n / t / 1e9}
-        t = timed(lambda: (ops.apply_moves(bufs[0], bufs[1], acts, n, CUBE, rew, done, code, _lib.FMT_CODE), bufs.reverse()))
-        extras["step_reward_done_code"] = {"steps_per_s": n / t, "GBps": 134 * n / t / 1e9}
-        m = 1 << 20                                                  # BASELINE config 2: batch 1M, apply_move + reward
-        a1, b1 = ops.alloc_states(m, CUBE, dev), ops.alloc_states(m, CUBE, dev)
-        ops.fill_solved(a1, m, CUBE)
-        ops.scramble(a1, m, CUBE, 20, seed=1234)
-        pp = [a1, b1]
-        t = timed(lambda: (ops.apply_moves(pp[0], pp[1], acts, m, CUBE, rew, done), pp.reverse()), iters=200)
-        extras["cfg2_step_reward_done_1M"] = {"steps_per_s": m / t, "GBps": 114 * m / t / 1e9, "launch_us": t * 1e6,
-                                              "note": "226 MB ping-pong working set fits the 256 MB Infinity Cache"}
-        oh = torch.empty((m, 20, 24), dtype=torch.float32, device=dev)
-        t = timed(lambda: ops.apply_moves(a, b, acts, m, CUBE, rew, done, oh, _lib.FMT_F32), iters=10)
-        extras["step_dense_f32_1M"] = {"steps_per_s": m / t, "GBps": (114 + 1920) * m / t / 1e9}
-        del oh
-        W, D = 100_000, 30
-        pt, ab = ops.adi_buffers(W, D, CUBE, dev, parents=True, children=True)      # 4096-walk tiles per (depth, child)
-        t = timed(lambda: ops.adi_generate(W, D, CUBE, pt, dev, seed=2024, **ab), iters=5)
-        extras["adi_100k_x30"] = {"units_per_s": W * D / t, "steps_per_s": 13 * W * D / t, "GBps": 715 * W * D / t / 1e9}
-        del ab
+    configs = None
+    if rank == 0 and world == 1 and not args.no_configs:
+        del a, b, bufs
+        torch.cuda.empty_cache()
+        configs = other_configs(torch, ops, _lib, dev, acts)
+        assert _lib.read_status(dev) == 0
 
     if rank == 0:
         steps_per_s = n * args.steps * world / elapsed
         launch_s = dev_ms * 1e-3 / args.steps
         achieved = BYTES_PER_STEP * n / launch_s / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-derived bytes per launch, if profiled
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("k_step_bytes_per_launch")
+                tj = json.load(open(tfile))
+                traffic = tj.get("k_step_bytes_per_launch")
+                traffic_source = (f"profiles/traffic.json: builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round {tj.get('round')} "
+                                  "over this same command (not re-measured in this run)")
             except Exception:
                 traffic = None
         out = {
@@ -225,14 +330,16 @@ def main():
                        "cubes_per_gpu": n, "bytes_per_step_algorithmic": BYTES_PER_STEP,
                        "parallelism": f"{world} independent ranks, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "k_step<Cube3,V,move,store>", "launch_us": launch_s * 1e6,
-                         "algorithmic_bytes_per_launch": BYTES_PER_STEP * n},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": "k_step<Cube3,2,move,store,POL1>", "launch_us": launch_s * 1e6,
+                         "algorithmic_bytes_per_launch": BYTES_PER_STEP * n,
+                         "note": "input rows streamed (nt), output rows written through and kept (sc0 sc1): the next launch finds part of "
+                                 "its input in the 256 MB Infinity Cache, so DRAM traffic is below the fabric traffic the counters show"},
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline()
-        if extras:
-            out["extras"] = extras
+        if configs:
+            out["configs"] = configs
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -115,6 +115,15 @@ int rc_apply_moves_ex(const uint8_t *in, uint8_t *out, const uint8_t *actions, i
 int rc_facade_step(uint8_t *st, int64_t pitch, int cube_size, int action, uint8_t *host_out,
                    uint32_t seq, int wait, void *stream);
 
+/* Node expansion of a single-root tree search for ONE cube (cube 0 of st; MCTS.expand, mcts.py:83-113: the
+ * reference does 12 env.step + 13 deepcopy(env) per leaf; also the child loop of get_target_value,
+ * cube_env.py:212-236).  One launch, results in `host_out` (host-mapped pinned memory, as above; 512 bytes,
+ * or 512 + A*R*C = 6272 with dense != 0): [0, SLOTS) the cube's own compact code (RC_FMT_CODE bytes: the node
+ * key), [32 + a * SLOTS, ...) the code of child a, [288 + a] solved flag of child a, [504..507] `seq`,
+ * and with dense != 0 [512 + a * R*C, ...) the dense uint8 one-hot of child a. */
+int rc_facade_expand(const uint8_t *st, int64_t pitch, int cube_size, uint8_t *host_out, uint32_t seq,
+                     int dense, int wait, void *stream);
+
 /* `depth` moves applied in place to every cube: the scramble loop of CubeEnv.reset
  * (cube_env.py:65-67) for n_cubes cubes at once.  actions_in[d * act_pitch + n] replays given
  * moves (e.g. the host's legacy-numpy draws, for bit-exact reset(seed)); NULL draws them on

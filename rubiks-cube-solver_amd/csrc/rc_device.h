@@ -525,6 +525,7 @@ __device__ __forceinline__ void dense_write(const uint8_t *lds_code, int tp, E *
     constexpr int EPT = 16 / (int)sizeof(E);  // elements per 16-byte store
     const uint32_t total = (uint32_t)ncubes * T::R * T::C;
     const uint32_t chunks = (total + EPT - 1) / EPT;
+    const __amdgpu_buffer_rsrc_t srd = make_srd(out);                           // `out` is workgroup-uniform
     for (uint32_t ch = tid; ch < chunks; ch += nthreads) {
         const uint32_t e0 = ch * EPT;
         uint32_t w[4];
@@ -547,8 +548,9 @@ __device__ __forceinline__ void dense_write(const uint8_t *lds_code, int tp, E *
             }
         }
         if (e0 + EPT <= total) {
-            u32x4 u = {w[0], w[1], w[2], w[3]};
-            __builtin_nontemporal_store(u, reinterpret_cast<u32x4 *>(out + e0));
+            Pk<4> u;
+            u.d[0] = w[0]; u.d[1] = w[1]; u.d[2] = w[2]; u.d[3] = w[3];
+            bst<4, kAuxStreamStore>(srd, e0 * (uint32_t)sizeof(E), 0, u);      // write-once stream (tile bytes < 2^32)
         } else {  // ragged end (2x2x2 only: 147 elements per cube)
             for (uint32_t j = 0; e0 + j < total; ++j) {
                 const uint32_t bit = j * (uint32_t)sizeof(E) * 8u;   // element j inside the 128-bit chunk

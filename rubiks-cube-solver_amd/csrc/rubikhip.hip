@@ -161,8 +161,9 @@ template <class T, class E, bool MOVE, bool STORE, int TILE>
 __global__ void __launch_bounds__(kDenseBlock) k_step_dense(StepArgs a, E *dense) {
     constexpr int TP = TILE + 4;
     __shared__ __attribute__((aligned(16))) uint8_t lds_code[T::SLOTS * TP];
-    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
     const uint32_t lo = threadIdx.x * 4;
+    // grid-stride over tiles: large batches run a capped grid (launch_dense_t), every workgroup a few tiles in turn
+    for (int64_t tile0 = (int64_t)blockIdx.x * TILE; tile0 < a.n; tile0 += (int64_t)gridDim.x * TILE) {
     const int64_t n0 = tile0 + lo;
     if (lo < TILE && n0 < a.n) {
         Pk<1> s[T::S];
@@ -200,14 +201,16 @@ __global__ void __launch_bounds__(kDenseBlock) k_step_dense(StepArgs a, E *dense
     const int64_t left = a.n - tile0;
     const int ncubes = left < TILE ? (int)left : TILE;
     dense_write<T, E>(lds_code, TP, dense + tile0 * (T::R * T::C), ncubes, threadIdx.x, kDenseBlock);
+    __syncthreads();                                               // the code tile is reused by the next iteration
+    }
 }
 
 template <class T, class E, int TILE>
 __global__ void __launch_bounds__(kDenseBlock) k_code_to_dense(const uint8_t *code, int64_t n, int64_t code_pitch, int shift, E *dense) {
     constexpr int TP = TILE + 4;
     __shared__ __attribute__((aligned(16))) uint8_t lds_code[T::SLOTS * TP];
-    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
     const uint32_t lo = threadIdx.x * 4;
+    for (int64_t tile0 = (int64_t)blockIdx.x * TILE; tile0 < n; tile0 += (int64_t)gridDim.x * TILE) {
     if (lo < TILE && tile0 + lo < n) {
         const uint8_t *row = code + tile_off(tile0, code_pitch, shift, T::SLOTS) + lo;
 #pragma unroll
@@ -217,6 +220,8 @@ __global__ void __launch_bounds__(kDenseBlock) k_code_to_dense(const uint8_t *co
     const int64_t left = n - tile0;
     const int ncubes = left < TILE ? (int)left : TILE;
     dense_write<T, E>(lds_code, TP, dense + tile0 * (T::R * T::C), ncubes, threadIdx.x, kDenseBlock);
+    __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------- expand
@@ -602,6 +607,62 @@ __global__ void __launch_bounds__(kWave) k_facade_step(uint8_t *st, uint32_t pit
     if (lane == 0) __hip_atomic_store(reinterpret_cast<uint32_t *>(host_out + kFacadeSeq), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// The node expansion of a single-root tree search (mcts.py:83-113: 12 env.step + 13 deepcopy per leaf) for ONE cube,
+// results straight into host-mapped memory like k_facade_step: [0, SLOTS) the cube's own compact code (its node key),
+// [32 + a * SLOTS ...) the code of child a, [288 + a] solved flag of child a, [504..507] sequence word; with `dense`
+// also [512 + a * R*C ...) the dense uint8 one-hot of child a (what get_target_value feeds the value net).
+constexpr int kFacadeChildCode = 32, kFacadeChildDone = 288, kFacadeDense = 512;
+
+template <class T>
+__global__ void __launch_bounds__(kWave) k_facade_expand(const uint8_t *st, uint32_t pitch, uint8_t *host_out, uint32_t seq, int dense) {
+    __shared__ __attribute__((aligned(4))) uint8_t out_lds[320];
+    const int lane = threadIdx.x;
+    Pk<1> s[T::S];
+#pragma unroll
+    for (int i = 0; i < T::S; ++i) s[i].d[0] = st[i * pitch];             // cube 0 only; uniform loads
+    FamilyCodes<T, 1> fam;
+    family_codes<T, 1>(s, fam);
+    if (lane == 0) {
+        Pk<1> pc[T::SLOTS];
+        family_pick<T, 1, -1>(fam, pc);
+#pragma unroll
+        for (int p = 0; p < T::SLOTS; ++p) out_lds[p] = (uint8_t)pc[p].d[0];
+        sfor<T::A>([&](auto ac) {
+            constexpr int a = decltype(ac)::value;
+            Pk<1> cc[T::SLOTS], c[T::S];
+            family_pick<T, 1, a>(fam, cc);
+#pragma unroll
+            for (int p = 0; p < T::SLOTS; ++p) out_lds[kFacadeChildCode + a * T::SLOTS + p] = (uint8_t)cc[p].d[0];
+            fixed_move<T, 1, a>(s, c);
+            out_lds[kFacadeChildDone + a] = (uint8_t)(done_bytes(unsolved<T, 1>(c)).d[0] & 1u);
+        });
+    }
+    __syncthreads();
+    for (int w = lane; w < 320 / 4; w += kWave) reinterpret_cast<uint32_t *>(host_out)[w] = reinterpret_cast<const uint32_t *>(out_lds)[w];
+    if (dense) {
+        constexpr int RC_ = T::R * T::C;                                  // 480 | 147 bytes per child
+        for (int w = lane; w < (T::A * RC_ + 3) / 4; w += kWave) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = 4 * w + j;
+                if (e < T::A * RC_) {
+                    const int a = e / RC_, x = e - a * RC_, r = x / T::C, col = x - r * T::C;
+                    const uint8_t *code = out_lds + kFacadeChildCode + a * T::SLOTS;
+                    bool one;
+                    if constexpr (T::SIZE == 3) one = code[r] == col;
+                    else { const int slot = col / 3, ori = col - slot * 3; one = code[slot] == r * 3 + ori; }
+                    if (one) word |= 1u << (8 * j);
+                }
+            }
+            reinterpret_cast<uint32_t *>(host_out + kFacadeDense)[w] = word;
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (lane == 0) __hip_atomic_store(reinterpret_cast<uint32_t *>(host_out + kFacadeSeq), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // read-and-clear of the status word in one atomic, result into host-mapped memory
 __global__ void k_read_status(uint32_t *host_word) { *host_word = atomicExch(&g_status, 0u); }
 
@@ -701,10 +762,16 @@ inline int dense_tile(int64_t n, int variant) {
     return n >= ((int64_t)1 << 17) ? 256 : 64;
 }
 
+// The dense kernels loop over tiles (grid-stride).  f32 rows (1920 B per cube) run 5 % faster at 1M cubes when the grid is
+// capped at the 2048 workgroups the chip holds at once (8 per CU), each taking tiles b, b + 2048, ...: 330 us against 347
+// (tools/exp/dense_exp.py); the 1- and 2-byte formats show no gain and keep one workgroup per tile.
+inline int64_t dense_grid(int64_t blocks, int fmt) { return fmt == RC_FMT_F32 && blocks > 2048 ? 2048 : blocks; }
+
 template <class T, bool MOVE, bool STORE, int TILE>
 int launch_dense_t(const StepArgs &a, void *onehot, int fmt, hipStream_t st) {
-    const int64_t blocks = (a.n + TILE - 1) / TILE;
+    int64_t blocks = (a.n + TILE - 1) / TILE;
     RC_GRID(blocks);
+    blocks = dense_grid(blocks, fmt);
     const dim3 g((unsigned)blocks), b(kDenseBlock);
     if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_step_dense<T, uint8_t, MOVE, STORE, TILE>), g, b, 0, st, a, static_cast<uint8_t *>(onehot));
     else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_step_dense<T, uint16_t, MOVE, STORE, TILE>), g, b, 0, st, a, static_cast<uint16_t *>(onehot));
@@ -724,8 +791,9 @@ int launch_dense(const StepArgs &a, void *onehot, int fmt, hipStream_t st, int v
 
 template <class T, int TILE>
 int launch_code_to_dense(const uint8_t *code, int64_t n, int64_t code_pitch, int sh, void *onehot, int fmt, hipStream_t st) {
-    const int64_t blocks = (n + TILE - 1) / TILE;
+    int64_t blocks = (n + TILE - 1) / TILE;
     RC_GRID(blocks);
+    blocks = dense_grid(blocks, fmt);
     const dim3 g((unsigned)blocks), b(kDenseBlock);
     if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_code_to_dense<T, uint8_t, TILE>), g, b, 0, st, code, n, code_pitch, sh, static_cast<uint8_t *>(onehot));
     else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_code_to_dense<T, uint16_t, TILE>), g, b, 0, st, code, n, code_pitch, sh, static_cast<uint16_t *>(onehot));
@@ -1006,6 +1074,8 @@ int rc_adi_targets(const float *child_value, const uint8_t *child_solved, const 
     return RC_OK;
 }
 
+static int facade_wait(uint8_t *host_out, uint32_t seq, void *stream, const char *who);
+
 int rc_facade_step(uint8_t *stp, int64_t pitch, int cube_size, int action, uint8_t *host_out, uint32_t seq, int wait, void *stream) {
     if (!stp || !host_out || pitch <= 0 || pitch * 54 >= ((int64_t)1 << 32)) return fail(RC_EINVAL, "rc_facade_step: bad arguments%s");
     if (action < 0 || action > 255) return fail(RC_EINVAL, "rc_facade_step: action out of the byte range%s");
@@ -1017,6 +1087,10 @@ int rc_facade_step(uint8_t *stp, int64_t pitch, int cube_size, int action, uint8
         return RC_OK;
     });
     if (rc != RC_OK || !wait) return rc;
+    return facade_wait(host_out, seq, stream, "rc_facade_step");
+}
+
+static int facade_wait(uint8_t *host_out, uint32_t seq, void *stream, const char *who) {
     // poll the sequence word the kernel writes last; fall back to a stream sync if it does not show up (e.g. host_out is not
     // host-visible memory), so a wrong buffer becomes an error instead of a hang
     volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(host_out + kFacadeSeq);
@@ -1026,7 +1100,20 @@ int rc_facade_step(uint8_t *stp, int64_t pitch, int cube_size, int action, uint8
     }
     RC_HIP(hipStreamSynchronize(S(stream)));
     if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return RC_OK;
-    return fail(RC_EHIP, "rc_facade_step: the result never reached host_out (is it host-mapped pinned memory?)%s");
+    return fail(RC_EHIP, "%s: the result never reached host_out (is it host-mapped pinned memory?)", who);
+}
+
+int rc_facade_expand(const uint8_t *stp, int64_t pitch, int cube_size, uint8_t *host_out, uint32_t seq, int dense, int wait, void *stream) {
+    if (!stp || !host_out || pitch <= 0 || pitch * 54 >= ((int64_t)1 << 32)) return fail(RC_EINVAL, "rc_facade_expand: bad arguments%s");
+    if (seq == 0) return fail(RC_EINVAL, "rc_facade_expand: seq must be non-zero%s");
+    const int rc = by_size(cube_size, [&](auto t) {
+        using T = decltype(t);
+        hipLaunchKernelGGL((k_facade_expand<T>), dim3(1), dim3(kWave), 0, S(stream), stp, (uint32_t)pitch, host_out, seq, dense);
+        RC_HIP(hipGetLastError());
+        return RC_OK;
+    });
+    if (rc != RC_OK || !wait) return rc;
+    return facade_wait(host_out, seq, stream, "rc_facade_expand");
 }
 
 int rc_read_status(uint32_t *status, void *stream) {

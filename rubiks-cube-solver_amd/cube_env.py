@@ -13,6 +13,7 @@ Differences that are deliberate and documented in DESIGN.md:
 from __future__ import annotations
 
 import copy
+import ctypes
 
 import numpy as np
 import torch
@@ -47,7 +48,7 @@ class CubeEnv:
         self._vec = _backend
         self._sim_cache = None
         self._cube_cache = None
-        self._fast = None  # (device result buffer, pinned host mirror, pinned action) for the one-copy step path
+        self._fast = None  # pinned result buffer + cached call arguments of the facade step path
         self.init_state()
 
     # ------------------------------------------------------------------ state attributes
@@ -118,23 +119,46 @@ class CubeEnv:
         self._cube_cache = onehot.astype(np.int64) if self.cube_size == 3 else onehot.astype(np.float64)
         return self._cube_cache, (1.0 if solved else -1.0), solved, {}
 
-    def _step_device(self, idx):
-        """One launch, one small upload and ONE download: the dense uint8 one-hot and the done flag share a
-        512-byte device buffer ([0:R*C] one-hot, [496] done)."""
-        v = self._vec
-        R, C = self.state_dim
+    def _facade(self):
+        """Pinned host buffer + cached call arguments of the two batch-1 entry points (rc_facade_step / rc_facade_expand):
+        the kernels write their results straight into host memory and the library spins on a sequence word -- no
+        upload, no download, no stream synchronisation (include/rubikhip.h)."""
         if self._fast is None:
-            dev_buf = torch.zeros(512, dtype=torch.uint8, device=v.device)
-            self._fast = (dev_buf, torch.zeros(512, dtype=torch.uint8).pin_memory(), torch.zeros(16, dtype=torch.uint8).pin_memory(),
-                          torch.zeros(16, dtype=torch.uint8, device=v.device))
-        dev_buf, host_buf, host_act, dev_act = self._fast
-        host_act[0] = idx
-        dev_act.copy_(host_act, non_blocking=True)
-        ops.apply_moves(v.stickers, v.stickers, dev_act, 1, self.cube_size, None, dev_buf[496:512], dev_buf[:R * C].view(1, R, C), _lib.FMT_U8)
-        host_buf.copy_(dev_buf, non_blocking=True)
-        torch.cuda.current_stream(v.device).synchronize()
-        h = host_buf.numpy()
+            v = self._vec
+            host = torch.zeros(8192, dtype=torch.uint8).pin_memory()
+            L = _lib.lib()
+            _lib.init(v.device)
+            self._fast = [host, host.numpy(), ctypes.c_void_p(host.data_ptr()), ctypes.c_void_p(v.stickers.data_ptr()),
+                          int(v.stickers.shape[-1]), 0, L.rc_facade_step, L.rc_facade_expand]
+        f = self._fast
+        f[5] = (f[5] % 0xFFFFFFFF) + 1
+        return f
+
+    def _step_device(self, idx):
+        f = self._facade()
+        v = self._vec
+        rc = f[6](f[3], f[4], self.cube_size, idx, f[2], f[5], 1, ctypes.c_void_p(torch.cuda.current_stream(v.device).cuda_stream))
+        if rc:
+            _lib.check(rc)
+        R, C = self.state_dim
+        h = f[1]
         return h[:R * C].reshape(R, C), bool(h[496])
+
+    def expand_host(self, dense=False):
+        """All children of the CURRENT state in one launch, results on the host (mcts.py:83-113, cube_env.py:212-236):
+        (own compact code bytes, child codes uint8 [A, SLOTS], child solved bool [A][, child one-hots uint8 [A, R, C]])."""
+        f = self._facade()
+        v = self._vec
+        rc = f[7](f[3], f[4], self.cube_size, f[2], f[5], int(dense), 1, ctypes.c_void_p(torch.cuda.current_stream(v.device).cuda_stream))
+        if rc:
+            _lib.check(rc)
+        A, SL = self.action_dim, ops.N_SLOTS[self.cube_size]
+        h = f[1]
+        out = (h[:SL].tobytes(), h[32:32 + A * SL].reshape(A, SL).copy(), h[288:288 + A].astype(bool))
+        if dense:
+            R, C = self.state_dim
+            out += (h[512:512 + A * R * C].reshape(A, R, C).copy(),)
+        return out
 
     def sim_state_to_state(self, sim_state):
         """One-hot of an arbitrary sticker vector (cube_env.py:132-152)."""
@@ -189,16 +213,23 @@ class CubeEnv:
         """(target_value, target_policy, error) of the CURRENT state (cube_env.py:196-252)."""
         if self.cube_size not in (2, 3):
             raise NotImplementedError
-        ex = self._vec.expand(codes=True)
-        solved = ex["child_solved"][:, 0].cpu().numpy().astype(bool)
+        if hasattr(self._vec, "stickers"):
+            _, _, solved, child_onehot = self.expand_host(dense=True)
+        else:  # test-only backends
+            ex = self._vec.expand(codes=True)
+            solved = ex["child_solved"][:, 0].cpu().numpy().astype(bool)
+            child_onehot = None
         reward = -1.0
         if solved.any():  # lowest solved action wins, value exactly 1.0 (cube_env.py:229-232)
             reward, target_value, target_policy = 1.0, 1.0, int(np.argmax(solved))
         if reward != 1.0:
             A = self.action_dim
-            dense = torch.empty((A, *self.state_dim), dtype=torch.float32, device=self._vec.device)
-            for a in range(A):
-                ops.onehot_from_code(ex["child_code"][a], 1, self.cube_size, dense[a:a + 1])
+            if child_onehot is not None:
+                dense = torch.from_numpy(child_onehot).float()
+            else:
+                dense = torch.empty((A, *self.state_dim), dtype=torch.float32, device=self._vec.device)
+                for a in range(A):
+                    ops.onehot_from_code(ex["child_code"][a], 1, self.cube_size, dense[a:a + 1])
             next_state_tensor = dense.to(self.device)
             reward_tensor = torch.tensor([-1.0] * A, device=self.device)
             with torch.no_grad():

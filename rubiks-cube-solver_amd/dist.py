@@ -9,8 +9,14 @@ from __future__ import annotations
 
 import os
 
-import torch
-import torch.distributed as dist
+# RCCL and tensor sharing between processes need dmabuf IPC on this driver stack.  The variable is read when the HIP
+# runtime initialises, so it is set at IMPORT time (import this module before the first GPU call of the process; the
+# launcher normally exports it already) -- setting it inside init() would come too late in a process that already
+# touched the GPU.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 def world():
@@ -35,7 +41,9 @@ def init(backend=None, device=None):
     """Initialise the default process group when launched with WORLD_SIZE > 1 (reporting only)."""
     rank, ws, local = world()
     if ws > 1 and not dist.is_initialized():
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0" and torch.cuda.is_initialized():
+            raise RuntimeError("HSA_ENABLE_IPC_MODE_LEGACY=0 must be exported before the process first touches the GPU "
+                               "(RCCL needs dmabuf IPC here)")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}

@@ -43,13 +43,13 @@ class _Node:
 
 
 def _puct_best(node, c):
+    """mcts.py:132-154 with the reference's arithmetic types: `policy[i]` stays the numpy float32 scalar it is in the
+    reference, so `c * P * x + W - L` is evaluated exactly as there (float32 under numpy >= 2) and near ties fall the
+    same way; `max(range(A), key=...)` = first maximal index."""
     total = sum(node.visits)
-    best, arg = -math.inf, 0
-    for i in range(len(node.children)):
-        s = c * float(node.policy[i]) * (math.sqrt(total) / (1 + node.visits[i])) + node.value[i] - node.vloss[i]
-        if s > best:
-            best, arg = s, i
-    return arg
+    root = math.sqrt(total)
+    score = [c * node.policy[i] * (root / (1 + node.visits[i])) + node.value[i] - node.vloss[i] for i in range(len(node.children))]
+    return max(range(len(score)), key=score.__getitem__)
 
 
 class MCTS:
@@ -67,11 +67,19 @@ class MCTS:
 
     @staticmethod
     def key_of(env):
-        """Node key of the env's current state: its compact one-hot code."""
-        v = env._vec
-        code = ops.alloc_code(1, v.cube_size, v.device)
-        ops.encode(v.stickers, 1, v.cube_size, code, _lib.FMT_CODE)
-        return ops.to_aos(code, 1)[0].cpu().numpy().tobytes()
+        """Node key of the env's current state: its compact one-hot code (one launch, no download)."""
+        return env.expand_host()[0]
+
+    def key_of_state(self, state):
+        """Node key of a one-hot state array, on the host: the reference keys nodes by np.array2string(state)
+        (mcts.py:66); the compact code is the same information (one column index per row)."""
+        s = np.asarray(state)
+        if self.cube_size == 3:
+            return s.argmax(-1).astype(np.uint8).tobytes()          # row = slot, column = code
+        col = s.argmax(-1)                                           # row = piece: column = slot*3 + ori (cube_env.py:143-147)
+        code = np.zeros(len(col), np.uint8)
+        code[col // 3] = np.arange(len(col)) * 3 + col % 3
+        return code.tobytes()
 
     def train(self, state, env):
         sim = copy.deepcopy(env)  # mcts.py:37 (one clone per simulation instead of 14)
@@ -87,7 +95,7 @@ class MCTS:
 
     def traverse(self, state, env):
         path, actions = [], []
-        current = self.key_of(env)
+        current = self.key_of_state(state)                          # mcts.py:66: the root is keyed by the `state` argument
         while True:
             node = self.children_and_data.get(current)
             if node is None or not node.children:
@@ -100,20 +108,20 @@ class MCTS:
             current = node.children[a]
 
     def expand(self, leaf_key, env):
-        """mcts.py:83-113 with one expansion launch instead of 12 steps + 13 deep copies."""
+        """mcts.py:83-113 with ONE launch (rc_facade_expand: child codes + solved flags land in pinned host memory)
+        instead of 12 steps + 13 deep copies."""
         value, policy = self.model.predict(env.cube)
-        ex = env._vec.expand(codes=True)
-        codes = np.stack([ops.to_aos(ex["child_code"][a], 1)[0].cpu().numpy() for a in range(self.action_dim)])
-        solved = ex["child_solved"][:, 0].cpu().numpy().astype(bool)
-        self.children_and_data[leaf_key] = _Node([c.tobytes() for c in codes], policy, self.value_min, list(solved))
+        _, codes, solved = env.expand_host()
+        self.children_and_data[leaf_key] = _Node([c.tobytes() for c in codes], policy, self.value_min, [bool(x) for x in solved])
         return value
 
     def backpropagate(self, path, actions, reward):
-        r = float(np.asarray(reward).reshape(-1)[0])
+        r = np.asarray(reward).reshape(-1)[0]                       # stays the model's float32 (mcts.py:124-125)
         for key, a in zip(reversed(path), reversed(actions)):
             node = self.children_and_data[key]
             node.value[a] = max(node.value[a], r)
-            node.vloss[a] -= self.loss_constant  # mcts.py:127 hard-codes 150 = the config's virtual_loss_const
+            node.vloss[a] -= 150  # mcts.py:127: the literal 150, NOT virtual_loss_const (bug-compatible: a config with another
+            #                       constant keeps a residual virtual loss in the reference, and so here)
             node.visits[a] += 1
 
     def get_most_promising_action_index(self, key):
@@ -248,9 +256,11 @@ class BatchedMCTS:
             if key == b"root":
                 tree[leaf_code[r].tobytes()] = tree[key]
             for node, a in reversed(trail):
-                node.value[a] = max(node.value[a], float(value[r]))
-                node.vloss[a] -= self.vl
+                node.value[a] = max(node.value[a], value[r])         # numpy float32, as in the reference
+                node.vloss[a] -= 150                                 # mcts.py:127 (literal)
                 node.visits[a] += 1
             if solved[r].any():
                 self.solution[r] = paths[r] + [int(np.argmax(solved[r]))]
+        if self.sims_used and max(self.sims_used) % 16 == 0 and _lib.read_status(self.dev) & _lib.STATUS_BAD_ACTION:
+            raise IndexError("action out of range")                 # cube_env.py:86,96
         return sum(s is not None for s in self.solution)

@@ -70,6 +70,7 @@ def greedy_rollout(model, env: VecCubeEnv, max_timesteps, mask=False, sync_every
         steps_done = t
         if t % sync_every == 0 and not bool(active.any()):
             break
+    env.check_actions()   # the device cannot raise mid-launch: surface an out-of-range action (IndexError, cube_env.py:86,96) here
     return {"solved": solve_step > 0, "solve_step": solve_step, "actions": taken[:steps_done]}
 
 

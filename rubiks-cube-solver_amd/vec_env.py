@@ -39,7 +39,7 @@ class VecCubeEnv:
     """
 
     def __init__(self, num_envs, device="cuda", cube_size=3, obs="onehot", onehot_dtype=torch.float32,
-                 seed=0, stream_id=0):
+                 seed=0, stream_id=0, debug_check_every=0):
         self.state_dim, self.action_dim = get_env_config(cube_size)
         self.cube_size = cube_size
         self.num_envs = int(num_envs)
@@ -54,6 +54,7 @@ class VecCubeEnv:
         self.action_names = list(ACTION_NAMES[cube_size])
         self.seed, self.stream_id = int(seed), int(stream_id)
         self._resets = 0
+        self._steps, self.debug_check_every = 0, int(debug_check_every)
         n, dev = self.num_envs, self.device
         self.stickers = ops.alloc_states(n, cube_size, dev)
         self.reward = torch.empty(n, dtype=torch.float32, device=dev)
@@ -125,8 +126,16 @@ class VecCubeEnv:
         """One face turn per cube.  actions: uint8 tensor [N] on the env's device (anything else is
         converted and range-checked).  active: optional bool tensor [N]; cubes where it is False get
         the no-op (they keep their state; used by batched rollouts to park solved cubes).
-        Returns (obs, reward float32 [N] of +-1.0, done uint8 [N], {}) -- cube_env.py:71-111."""
+        Returns (obs, reward float32 [N] of +-1.0, done uint8 [N], {}) -- cube_env.py:71-111.
+
+        The three returned tensors are the env's OWN buffers, overwritten by the next step / reset: clone what
+        must outlive it.  A uint8 device tensor is not range-checked on the host (that would synchronise): an
+        action > action_dim leaves that cube unspecified and raises IndexError at the next check_actions()
+        (`debug_check_every=K` in the constructor runs that check every K steps)."""
         a = self._actions(actions)
+        self._steps += 1
+        if self.debug_check_every and self._steps % self.debug_check_every == 0:
+            self.check_actions()
         if active is not None:
             a = torch.where(active.to(self.device), a, torch.full_like(a, self.action_dim))
         ops.apply_moves(self.stickers, self.stickers, a, self.num_envs, self.cube_size, self.reward, self.done,
@@ -187,6 +196,8 @@ class VecCubeEnv:
     # ------------------------------------------------------------------------------- helpers
     def _actions(self, actions):
         a = actions
+        if isinstance(a, torch.Tensor) and a.numel() != self.num_envs:
+            raise ValueError(f"need {self.num_envs} actions")
         if not (isinstance(a, torch.Tensor) and a.dtype == torch.uint8 and a.device == self.device):
             a = torch.as_tensor(np.asarray(actions) if not isinstance(actions, torch.Tensor) else actions)
             if a.numel() != self.num_envs:

@@ -80,3 +80,19 @@ def test_checkpoint_policy_solves_our_222_cubes():
     print("2x2x2 greedy solve rate of the shipped checkpoint on the restated env:", rates)
     # a convention mismatch leaves the net blind: solve rates would sit near chance even at depth 1-2
     assert rates[1] >= 0.9 and rates[2] >= 0.9 and rates[4] >= 0.8
+
+
+def test_fixture_matches_live_checkpoint_run():
+    """tests/golden/crosscheck_222.npz (actions and outcomes of the run above, no weights) is what the checkpoint does
+    on the restated env today: regenerate a slice and compare."""
+    from oracle.oracle_np import OracleCubeEnv
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "crosscheck_222.npz"))
+    sd = read_state_dict_statically(CKPT)
+    env = OracleCubeEnv(None, 2)
+    for i in range(0, len(g["seeds"]), 7):
+        state = env.reset(seed=int(g["seeds"][i]), scramble_count=int(g["ks"][i]))
+        for t in range(int(g["solve_step"][i])):
+            a = int(np.argmax(policy_logits(sd, state[None].astype(np.float32))[0]))
+            assert a == g["actions"][i, t]
+            state, _, d, _ = env.step(a)
+            assert (np.argmax(state, 1) == g["cols"][i, t]).all() and d == g["done"][i, t]

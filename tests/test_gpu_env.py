@@ -100,7 +100,12 @@ def test_get_random_samples_matches_reference_golden(mod, golden):
     for _ in range(n):
         np.random.randint(12, size=30)
     assert (np.random.get_state()[1] == after).all()             # consumed exactly the reference's draws
-    tv_ok = 0
+    # child values of the stub model, from the oracle's child codes: a policy mismatch is only acceptable on an arg-max TIE
+    from oracle.oracle_np import Oracle
+    out = Oracle().adi(3, n, 30, actions_in=g["actions"], want_children=False)
+    wv = g["w"].reshape(20, 24).astype(np.float64)
+    v = np.sort(wv[np.arange(20), out["child_code"].astype(np.int64)].sum(-1), -1)                 # [n, 30, 12] ascending
+    gap = v[..., -1] - v[..., -2]
     for i, smp in enumerate(buf):
         c, d = divmod(i, 30)
         assert set(smp) == {"state", "target_value", "target_policy", "scramble_count", "error"}
@@ -109,8 +114,8 @@ def test_get_random_samples_matches_reference_golden(mod, golden):
         assert smp["scramble_count"] == d + 1
         assert smp["target_value"] == pytest.approx(g["target_value"][c, d], abs=1e-5)
         assert smp["error"] == pytest.approx(g["error"][c, d], abs=1e-5)
-        tv_ok += smp["target_policy"] == g["target_policy"][c, d]
-    assert tv_ok >= len(buf) - 2                                  # arg-max ties within float noise only
+        if smp["target_policy"] != g["target_policy"][c, d]:
+            assert gap[c, d] < 1e-5 and not out["child_solved"][c, d].any(), (c, d, gap[c, d])   # mismatch => top-2 tie
     assert all(b["target_value"] == 1.0 for b in buf[::30])      # depth 1: the inverse move solves
     assert (env.sim_cube == _final_state(g)).all()
 
@@ -140,7 +145,11 @@ def test_adi_samples_device_rng_and_gpu_model(mod, oracle, golden):
     tv = np.where(solved.any(-1), 1.0, v_child.max(-1))
     assert np.allclose(res["target_value"].cpu().numpy(), tv, atol=1e-5)
     tp = np.where(solved.any(-1), np.argmax(solved, -1), np.argmax(v_child, -1))
-    assert (res["target_policy"].cpu().numpy() == tp).mean() > 0.995
+    got_tp = res["target_policy"].cpu().numpy()
+    srt = np.sort(v_child, -1)
+    tie = (srt[..., -1] - srt[..., -2] < 1e-5) & ~solved.any(-1)
+    assert ((got_tp == tp) | tie).all()                                 # a mismatch is a top-2 tie within 1e-5, nothing else
+    assert (got_tp == tp).mean() > 0.995
     v_par = w[np.arange(20), exp["parent_code"].astype(np.int64)].sum(-1) + float(g["b"])
     err = np.abs(v_par - tv) * np.arange(1, D + 1, dtype=np.float64)[None, :] ** -0.3
     assert np.allclose(res["error"].cpu().numpy(), err, atol=1e-5)
@@ -454,14 +463,24 @@ def test_get_random_samples_with_reference_deepcube(mod, golden):
         np.random.seed(int(g["seed"]))
         env.get_random_samples(buf, net.to(device), depth, n, float(g["temperature"]))
         assert len(buf) == n * depth
-        same_policy = 0
         for i, smp in enumerate(buf):
             c, d = divmod(i, depth)
             assert (np.argmax(smp["state"], 1) == g["cols"][c, d]).all()
             assert smp["target_value"] == pytest.approx(g["target_value"][c, d], abs=1e-5)
             assert smp["error"] == pytest.approx(g["error"][c, d], abs=1e-5)
-            same_policy += smp["target_policy"] == g["target_policy"][c, d]
-        assert same_policy >= len(buf) - 1
+            if smp["target_policy"] != g["target_policy"][c, d]:       # only on a top-2 tie of the child values (< 1e-5)
+                from oracle.oracle_np import Oracle
+                orc = Oracle()
+                st = orc.solved(3, 1)
+                np.random.seed(int(g["seed"]))
+                walks = [np.random.randint(12, size=depth) for _ in range(n)]
+                for a in walks[c][:d + 1]:
+                    st = orc.step(3, st, np.array([a], np.uint8))[0]
+                ch, cc, cso = orc.expand(3, st)
+                oh = torch.nn.functional.one_hot(torch.from_numpy(cc[0].astype(np.int64)), 24).float()
+                with torch.no_grad():
+                    vals = np.sort(net.cpu()(oh)[0].reshape(-1).double().numpy())
+                assert vals[-1] - vals[-2] < 1e-5 and not cso.any(), (c, d)
 
 
 def test_reference_named_operators(mod, golden):
@@ -494,3 +513,119 @@ def test_reference_named_operators(mod, golden):
     assert P.isSolved(s) and (P.getStickers(P.getOP(P.doMove(s, "F"))) == P.doMove(s, "F")).all()
     with pytest.raises(KeyError):
         P.doMove(s, "D")                                       # the 2x2x2 env only turns U, F, R (cube_env.py:25)
+
+
+@pytest.mark.parametrize("cs", [3, 2])
+def test_facade_step_and_expand_entry_points(mod, oracle, cs):
+    """rc_facade_step / rc_facade_expand (the batch-1 latency path: results land in pinned host memory, no copies, no
+    stream sync) against the oracle over a long random walk, incl. solved hits; keys from the one-hot state equal the
+    device code (cube_env.py:71-111, mcts.py:66,83-113)."""
+    from rubiks_cube_solver_amd.mcts_batched import MCTS
+    A = 12 if cs == 3 else 6
+    env = mod.make_env(torch.device("cpu"), cs)
+    cfg = {"mcts": {"virtual_loss_const": 150, "cpuct": 1.0, "value_min": -10.0}, "test": {"cube_size": cs}}
+    tree = MCTS(None, cfg)
+    rng = np.random.default_rng(cs)
+    acts = list(rng.integers(0, A, 300))
+    acts[10:12] = [2, 3]                                   # X then X': back to the state 10 moves in
+    st = oracle.solved(cs, 1)
+    n_solved = 0
+    for i, a in enumerate([0, 1] + acts):                  # the first two moves end on the solved cube
+        st, code, done, rew = oracle.step(cs, st, np.array([a], np.uint8))
+        s, r, d, _ = env.step(int(a))
+        assert r == float(rew[0]) and d == bool(done[0])
+        n_solved += d
+        own, child_code, child_solved = env.expand_host()
+        assert own == code[0].tobytes() == tree.key_of_state(s) == MCTS.key_of(env)
+        ch, cc, cso = oracle.expand(cs, st)
+        assert (child_code == cc[0]).all() and (child_solved == cso[0].astype(bool)).all()
+        if i % 50 == 0:
+            _, _, _, dense = env.expand_host(dense=True)
+            _, oh = oracle.encode(cs, ch[0])
+            assert (dense == oh).all()
+    assert n_solved >= 1
+    assert (env.sim_cube == st[0]).all()
+
+
+def _mp_child(rank, n, steps, seed, q):
+    """Fresh process (spawn): its own VecCubeEnv on the shared GPU with stream_id = rank; reports its action draws and
+    final stickers."""
+    import numpy as np
+    import torch
+    import rubiks_cube_solver_amd as r
+    env = r.VecCubeEnv(n, "cuda", 3, obs="code", seed=seed, stream_id=rank)
+    env.reset(scramble_count=5)
+    g = torch.Generator(device="cuda").manual_seed(100 + rank)
+    for _ in range(steps):
+        env.step(torch.randint(0, 12, (n,), generator=g, device="cuda", dtype=torch.uint8))
+    env.check_actions()
+    env2 = r.make_env(torch.device("cpu"), 3)               # the batch-1 facade in the same worker, like train.py:141
+    env2.reset(seed=rank * 10, scramble_count=7)
+    q.put((rank, env.sim_cube.cpu().numpy(), env2.sim_cube.copy()))
+
+
+def test_envs_in_several_processes_share_one_gpu(oracle, golden):
+    """train.py:85-92,141-147 runs one env per worker process.  Here 3 spawned processes each own a VecCubeEnv
+    (stream_id = rank) and a CubeEnv on the SAME GPU at once, 200 steps each; every rank's result equals the oracle's
+    replay of its own (seed, rank) stream and the ranks' streams differ.  Children are fresh processes (spawn): a
+    process that has touched the GPU is never forked."""
+    import multiprocessing as mp
+    import os
+    ctx = mp.get_context("spawn")
+    n, steps, seed, world = 3000, 200, 4242, 3
+    q = ctx.Queue()
+    env = dict(os.environ)
+    procs = [ctx.Process(target=_mp_child, args=(rank, n, steps, seed, q)) for rank in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, st, st1 = q.get(timeout=300)
+        got[rank] = (st, st1)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    finals = []
+    for rank in range(world):
+        # the device RNG stream of reset(): (seed, stream_id = rank, walk = resets * n + i), restated by the oracle
+        exp = oracle.adi(3, n, 5, seed=seed, stream=rank, walk0=n, want_children=False)["parents"][:, -1]
+        g = torch.Generator(device="cuda").manual_seed(100 + rank)
+        st = exp
+        for _ in range(steps):
+            a = torch.randint(0, 12, (n,), generator=g, device="cuda", dtype=torch.uint8).cpu().numpy()
+            st = oracle.step(3, st, a, threads=4)[0]
+        assert (got[rank][0] == st).all(), rank
+        finals.append(exp)
+        gr = golden("reset_333")                             # the facade's reset(seed = rank*10, 7) is the reference's
+        i, j = list(gr["seeds"]).index(rank * 10), list(gr["ks"]).index(7)
+        assert (got[rank][1] == gr["stickers"][i, j]).all(), rank
+    assert not (finals[0] == finals[1]).all() and not (finals[1] == finals[2]).all()
+
+
+def test_checkpoint_traces_replay_on_the_hip_222_path(mod, golden):
+    """SURVEY 8f N4 on the product path.  tests/golden/crosscheck_222.npz holds the greedy solve traces of the
+    reference's shipped 2x2x2 checkpoint (pretrained/222model.pt, model.py:47-76) for seeds 0..39 x k in
+    {1,2,3,4,6,8}: the scramble draws of reset(seed, k), the policy's actions and, per step, the arg-max column of every
+    one-hot row and the done flag.  Here the Cube2 KERNELS replay them: VecCubeEnv(cube_size=2).reset(seeds, ks) (numpy's
+    legacy generator on the device), then one rc_apply_moves per time step.  The authors' policy solving every one of
+    these cubes is the only external evidence for the unpinned 2x2x2 convention (cube_env.py:142-147); this test
+    carries it to the HIP code."""
+    g = golden("crosscheck_222")
+    n, T = g["actions"].shape
+    env = mod.VecCubeEnv(n, "cuda", 2, obs="onehot", onehot_dtype=torch.uint8)
+    env.reset(seeds=[int(s) for s in g["seeds"]], scramble_count=[int(k) for k in g["ks"]])
+    env2 = mod.VecCubeEnv(n, "cuda", 2, obs="onehot", onehot_dtype=torch.uint8)
+    env2.reset(actions=g["scramble"], scramble_count=8)                # the recorded draws, no-op padded
+    assert torch.equal(env.sim_cube, env2.sim_cube)                    # device MT19937 == the draws the fixture recorded
+    solve_step = np.zeros(n, np.int32)
+    for t in range(T):
+        obs, rew, done, _ = env.step(torch.from_numpy(np.ascontiguousarray(g["actions"][:, t])).cuda())
+        assert (obs.argmax(-1).cpu().numpy() == g["cols"][:, t]).all(), t
+        assert int(obs.sum()) == n * 7                                  # exactly one 1 per row
+        d = done.cpu().numpy()
+        assert (d == g["done"][:, t]).all(), t
+        assert (rew.cpu().numpy() == np.where(d, 1.0, -1.0)).all()
+        solve_step[(solve_step == 0) & (d != 0)] = t + 1
+    assert (solve_step == g["solve_step"]).all()
+    assert (solve_step > 0).all()                                       # the authors' policy solves every one of them
+    env.check_actions()

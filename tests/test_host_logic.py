@@ -264,14 +264,25 @@ d.barrier()
 '''
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return str(sock.getsockname()[1])
+
+
 def test_two_rank_gloo_sharding(tmp_path):
-    """world_size 2 on CPU (gloo): disjoint shards, rank-distinct RNG streams, reporting reductions only."""
+    """world_size 2 on CPU (gloo): disjoint shards, rank-distinct RNG streams, reporting reductions only.
+    This exercises the HOST side of the N>1 path only -- dist.py's shard / rng_stream / reductions, with the oracle
+    standing in for the per-rank generator; no kernel of librubikhip.so runs here.  The kernels' side of the same
+    contract (stream_id = rank on a shared GPU, one process each) is tests/test_gpu_env.py::
+    test_envs_in_several_processes_share_one_gpu and tests/test_bench_contract.py::test_bench_two_ranks_rehearsal."""
     import json
     script = tmp_path / "worker.py"
     script.write_text(_GLOO_WORKER)
     env = dict(os.environ, RC_ROOT=ROOT, RC_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", str(script)]
+           "--master-port", _free_port(), str(script)]
     subprocess.run(cmd, check=True, env=env, timeout=240, capture_output=True)
     r0, r1 = (json.load(open(tmp_path / f"r{i}.json")) for i in (0, 1))
     assert (r0["lo"], r0["hi"], r1["lo"], r1["hi"]) == (0, 501, 501, 1001)

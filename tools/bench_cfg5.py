@@ -45,7 +45,20 @@ def timeit(fn, iters=200, warm=20):
 
 
 @torch.no_grad()
-def main():
+def run(short=False):
+    """-> dict of microsecond timings.  short: fewer repetitions and no lockstep-search legs (bench.py's default line)."""
+    global timeit
+    if short:
+        full_timeit = timeit
+        timeit = lambda fn, iters=60, warm=10: full_timeit(fn, iters, warm)
+    try:
+        return _run(short)
+    finally:
+        if short:
+            timeit = full_timeit
+
+
+def _run(short):
     n, cs, dev = 4096, 3, torch.device("cuda")
     model = DeepCubeStandIn().to(dev).eval()
     leaves = ops.alloc_states(n, cs, dev)
@@ -110,6 +123,11 @@ def main():
     except Exception as e:
         res["hipgraph_overlapped_step_us"] = None
         res["hipgraph_overlap_error"] = str(e)[:200]
+    hidden = res["serial_step_us"] - res["overlapped_step_us"]
+    res["overlap_hidden_us"] = hidden
+    res["overlap_fraction_of_expand"] = hidden / res["expand_stickers_codes_flags_us"]
+    if short:
+        return res
     # the product's lockstep search: device part of one simulation (replay 8 moves + expand + one-hot + forward)
     import numpy as np
     from rubiks_cube_solver_amd.mcts_batched import BatchedMCTS
@@ -129,9 +147,11 @@ def main():
         for _ in range(20):
             bm.leaves_step(paths)
         res[f"batched_mcts_leaves_step_with_d2h_{name}_us"] = (time.perf_counter() - t0) / 20 * 1e6
-    hidden = res["serial_step_us"] - res["overlapped_step_us"]
-    res["overlap_hidden_us"] = hidden
-    res["overlap_fraction_of_expand"] = hidden / res["expand_stickers_codes_flags_us"]
+    return res
+
+
+def main():
+    res = run()
     print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in res.items()}))
 
 

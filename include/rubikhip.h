@@ -114,6 +114,11 @@ int rc_apply_moves_ex(const uint8_t *in, uint8_t *out, const uint8_t *actions, i
  * after the launch and the caller polls host_out itself.  Out-of-range actions set RC_STATUS_BAD_ACTION. */
 int rc_facade_step(uint8_t *st, int64_t pitch, int cube_size, int action, uint8_t *host_out,
                    uint32_t seq, int wait, void *stream);
+/* Same for a SEQUENCE of moves (`actions`: n_actions bytes in HOST memory, copied into the launch arguments; n_actions
+ * may be 0 = just report the current state): one launch per 60 moves instead of one per move; host_out describes the
+ * final state.  This is a whole tree descent of MCTS.traverse (mcts.py:52-81, one env.step per level there). */
+int rc_facade_steps(uint8_t *st, int64_t pitch, int cube_size, const uint8_t *actions, int n_actions,
+                    uint8_t *host_out, uint32_t seq, int wait, void *stream);
 
 /* Node expansion of a single-root tree search for ONE cube (cube 0 of st; MCTS.expand, mcts.py:83-113: the
  * reference does 12 env.step + 13 deepcopy(env) per leaf; also the child loop of get_target_value,

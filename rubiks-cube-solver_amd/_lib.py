@@ -38,6 +38,7 @@ def _declare(L):
     L.rc_apply_moves.argtypes = [vp, vp, vp, i64, i64, i64, i32, vp, vp, vp, i32, i64, vp]
     L.rc_apply_moves_ex.argtypes = [vp, vp, vp, i64, i64, i64, i32, vp, vp, vp, i32, i64, vp, i32]
     L.rc_facade_step.argtypes = [vp, i64, i32, i32, vp, ctypes.c_uint32, i32, vp]
+    L.rc_facade_steps.argtypes = [vp, i64, i32, vp, i32, vp, ctypes.c_uint32, i32, vp]
     L.rc_facade_expand.argtypes = [vp, i64, i32, vp, ctypes.c_uint32, i32, i32, vp]
     L.rc_scramble.argtypes = [vp, i64, i64, i32, i32, u64, u64, i64, vp, vp, i64, vp, vp, vp]
     L.rc_legacy_scramble_actions.argtypes = [vp, vp, i32, i32, i64, i32, vp, i64, vp]
@@ -50,7 +51,7 @@ def _declare(L):
     L.rc_adi_generate_ex.argtypes = [u64, u64, i64, i64, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32]
     L.rc_adi_targets.argtypes = [vp, vp, vp, vp, i64, i64, i32, vp, vp, vp, vp]
     L.rc_read_status.argtypes = [vp, vp]
-    for name in ("rc_init", "rc_get_tables", "rc_fill_solved", "rc_apply_moves", "rc_apply_moves_ex", "rc_facade_step", "rc_facade_expand", "rc_scramble",
+    for name in ("rc_init", "rc_get_tables", "rc_fill_solved", "rc_apply_moves", "rc_apply_moves_ex", "rc_facade_step", "rc_facade_steps", "rc_facade_expand", "rc_scramble",
                  "rc_legacy_scramble_actions", "rc_is_solved", "rc_encode", "rc_onehot_from_code", "rc_expand_children",
                  "rc_expand_children_ex", "rc_adi_generate", "rc_adi_generate_ex", "rc_adi_targets", "rc_read_status"):
         getattr(L, name).restype = i32

@@ -552,26 +552,37 @@ __global__ void __launch_bounds__(256) k_adi_targets(const float *child_value, c
 // [504..507] sequence (written last, after a system-scope fence).
 constexpr int kFacadeBytes = 512, kFacadeDone = 496, kFacadeSeq = 504;
 
+constexpr int kFacadeMaxActs = 60;
+struct FacadeActs {
+    uint32_t n;
+    uint8_t a[kFacadeMaxActs];
+};
+
 template <class T>
-__global__ void __launch_bounds__(kWave) k_facade_step(uint8_t *st, uint32_t pitch, uint32_t action, uint8_t *host_out, uint32_t seq) {
+__global__ void __launch_bounds__(kWave) k_facade_step(uint8_t *st, uint32_t pitch, FacadeActs acts, uint8_t *host_out, uint32_t seq) {
     __shared__ uint8_t code_lds[32];
     const int lane = threadIdx.x;
-    Pk<1> s[T::S];
-#pragma unroll
-    for (int i = 0; i < T::S; ++i) s[i].d[0] = st[i * pitch];             // cube 0 only; uniform loads
-    Pk<1> act;
-    act.d[0] = action & 0xffu;                                            // bytes 1..3 (pad cubes): action 0
-    Pk<1> m[T::A];
-    const Pk<1> bad = action_masks<T, 1>(act, m);
-    if (bad.d[0] & 0xffu) atomicOr(&g_status, RC_STATUS_BAD_ACTION);
     Pk<1> o[T::S];
-    apply_move<T, 1>(s, m, o);
+#pragma unroll
+    for (int i = 0; i < T::S; ++i) o[i].d[0] = st[i * pitch];             // cube 0 only; uniform loads
+    for (uint32_t k = 0; k < acts.n; ++k) {                               // the moves of one tree descent, in one launch
+        Pk<1> act;
+        act.d[0] = acts.a[k];                                             // bytes 1..3 (pad cubes): action 0
+        Pk<1> m[T::A];
+        const Pk<1> bad = action_masks<T, 1>(act, m);
+        if (bad.d[0] & 0xffu) atomicOr(&g_status, RC_STATUS_BAD_ACTION);
+        Pk<1> s[T::S];
+#pragma unroll
+        for (int i = 0; i < T::S; ++i) s[i] = o[i];
+        apply_move<T, 1>(s, m, o);
+    }
     if (lane < T::S) {
         // lane i stores sticker i: a run-time register index is avoided by a compile-time select chain
         uint32_t v = 0;
         sfor<T::S>([&](auto ic) { constexpr int i = decltype(ic)::value; if (lane == i) v = o[i].d[0]; });
         st[lane * pitch] = (uint8_t)v;
     }
+    if (seq == 0) return;                                                 // an intermediate launch of a long path: state only
     const Pk<1> dn = done_bytes(unsolved<T, 1>(o));
     Pk<1> c[T::SLOTS];
     encode<T, 1>(o, c);
@@ -1076,18 +1087,33 @@ int rc_adi_targets(const float *child_value, const uint8_t *child_solved, const 
 
 static int facade_wait(uint8_t *host_out, uint32_t seq, void *stream, const char *who);
 
-int rc_facade_step(uint8_t *stp, int64_t pitch, int cube_size, int action, uint8_t *host_out, uint32_t seq, int wait, void *stream) {
-    if (!stp || !host_out || pitch <= 0 || pitch * 54 >= ((int64_t)1 << 32)) return fail(RC_EINVAL, "rc_facade_step: bad arguments%s");
-    if (action < 0 || action > 255) return fail(RC_EINVAL, "rc_facade_step: action out of the byte range%s");
-    if (seq == 0) return fail(RC_EINVAL, "rc_facade_step: seq must be non-zero%s");
+int rc_facade_steps(uint8_t *stp, int64_t pitch, int cube_size, const uint8_t *actions, int n_actions, uint8_t *host_out, uint32_t seq,
+                    int wait, void *stream) {
+    if (!stp || !host_out || pitch <= 0 || pitch * 54 >= ((int64_t)1 << 32)) return fail(RC_EINVAL, "rc_facade_steps: bad arguments%s");
+    if (n_actions < 0 || (n_actions > 0 && !actions)) return fail(RC_EINVAL, "rc_facade_steps: bad action list%s");
+    if (seq == 0) return fail(RC_EINVAL, "rc_facade_steps: seq must be non-zero%s");
     const int rc = by_size(cube_size, [&](auto t) {
         using T = decltype(t);
-        hipLaunchKernelGGL((k_facade_step<T>), dim3(1), dim3(kWave), 0, S(stream), stp, (uint32_t)pitch, (uint32_t)action, host_out, seq);
-        RC_HIP(hipGetLastError());
+        int done = 0;
+        do {                                                       // up to 60 moves travel in the launch arguments
+            FacadeActs fa{};
+            const int m = n_actions - done < kFacadeMaxActs ? n_actions - done : kFacadeMaxActs;
+            fa.n = (uint32_t)m;
+            memcpy(fa.a, actions + done, (size_t)m);
+            done += m;
+            hipLaunchKernelGGL((k_facade_step<T>), dim3(1), dim3(kWave), 0, S(stream), stp, (uint32_t)pitch, fa, host_out, done == n_actions ? seq : 0u);
+            RC_HIP(hipGetLastError());
+        } while (done < n_actions);
         return RC_OK;
     });
     if (rc != RC_OK || !wait) return rc;
-    return facade_wait(host_out, seq, stream, "rc_facade_step");
+    return facade_wait(host_out, seq, stream, "rc_facade_steps");
+}
+
+int rc_facade_step(uint8_t *stp, int64_t pitch, int cube_size, int action, uint8_t *host_out, uint32_t seq, int wait, void *stream) {
+    if (action < 0 || action > 255) return fail(RC_EINVAL, "rc_facade_step: action out of the byte range%s");
+    const uint8_t a = (uint8_t)action;
+    return rc_facade_steps(stp, pitch, cube_size, &a, 1, host_out, seq, wait, stream);
 }
 
 static int facade_wait(uint8_t *host_out, uint32_t seq, void *stream, const char *who) {

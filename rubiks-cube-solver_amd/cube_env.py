@@ -129,7 +129,7 @@ class CubeEnv:
             L = _lib.lib()
             _lib.init(v.device)
             self._fast = [host, host.numpy(), ctypes.c_void_p(host.data_ptr()), ctypes.c_void_p(v.stickers.data_ptr()),
-                          int(v.stickers.shape[-1]), 0, L.rc_facade_step, L.rc_facade_expand]
+                          int(v.stickers.shape[-1]), 0, L.rc_facade_step, L.rc_facade_expand, L.rc_facade_steps]
         f = self._fast
         f[5] = (f[5] % 0xFFFFFFFF) + 1
         return f
@@ -143,6 +143,23 @@ class CubeEnv:
         R, C = self.state_dim
         h = f[1]
         return h[:R * C].reshape(R, C), bool(h[496])
+
+    def step_many(self, actions):
+        """Apply a whole action sequence in ONE launch (per 60 moves) and return (state, reward, done, {}) of the final
+        state, exactly what len(actions) successive step() calls leave behind -- a tree descent of MCTS.traverse
+        (mcts.py:52-81).  actions: ints 0..A-1 (IndexError otherwise, like step)."""
+        names = self.action_to_sim_action[self.cube_size]
+        acts = bytes(names.index(names[a]) for a in actions)        # same IndexError / TypeError as step()
+        f = self._facade()
+        v = self._vec
+        rc = f[8](f[3], f[4], self.cube_size, acts, len(acts), f[2], f[5], 1, ctypes.c_void_p(torch.cuda.current_stream(v.device).cuda_stream))
+        if rc:
+            _lib.check(rc)
+        R, C = self.state_dim
+        onehot, solved = f[1][:R * C].reshape(R, C), bool(f[1][496])
+        self._sim_cache = None
+        self._cube_cache = onehot.astype(np.int64) if self.cube_size == 3 else onehot.astype(np.float64)
+        return self._cube_cache, (1.0 if solved else -1.0), solved, {}
 
     def expand_host(self, dense=False):
         """All children of the CURRENT state in one launch, results on the host (mcts.py:83-113, cube_env.py:212-236):
@@ -259,7 +276,7 @@ class CubeEnv:
         other = object.__new__(CubeEnv)
         for k, v in self.__dict__.items():
             if k == "_vec":
-                other._vec = self._vec.clone()
+                other._vec = self._vec.clone(lean=True) if hasattr(self._vec, "stickers") else self._vec.clone()
             elif k == "device":
                 other.device = self.device
             elif k == "_fast":

@@ -94,18 +94,27 @@ class MCTS:
         return None
 
     def traverse(self, state, env):
+        """mcts.py:52-81.  The reference steps the env once per tree level; the descent only needs the tree (child keys are
+        stored in the nodes), so the actions are collected on the host and the env makes the whole descent in ONE launch
+        (CubeEnv.step_many) -- it ends on the same leaf state."""
         path, actions = [], []
         current = self.key_of_state(state)                          # mcts.py:66: the root is keyed by the `state` argument
         while True:
             node = self.children_and_data.get(current)
             if node is None or not node.children:
-                return path, actions, current
+                break
             a = random.randint(0, self.action_dim - 1) if sum(node.visits) == 0 else _puct_best(node, self.exploration_constant)
             path.append(current)
             actions.append(a)
             node.vloss[a] += self.loss_constant
-            env.step(a)
             current = node.children[a]
+        if actions:
+            if hasattr(env, "step_many"):
+                env.step_many(actions)
+            else:
+                for a in actions:
+                    env.step(a)
+        return path, actions, current
 
     def expand(self, leaf_key, env):
         """mcts.py:83-113 with ONE launch (rc_facade_expand: child codes + solved flags land in pinned host memory)

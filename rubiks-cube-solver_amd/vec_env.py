@@ -180,12 +180,16 @@ class VecCubeEnv:
         if _lib.read_status(self.device) & _lib.STATUS_BAD_ACTION:
             raise IndexError("action out of range")  # cube_env.py:86,96
 
-    def clone(self):
+    def clone(self, lean=False):
+        """Independent copy of the cubes.  lean: copy only the sticker buffer (the state); reward / done / observation
+        are outputs of the next step and get fresh uninitialised buffers -- one copy kernel instead of four (the batch-1
+        facade, which mcts.py:37 deep-copies once per simulation, keeps its observation on the host)."""
         other = object.__new__(VecCubeEnv)
         other.__dict__.update(self.__dict__)
-        for k in ("stickers", "reward", "done", "_obs_buf"):
+        other.stickers = self.stickers.clone()
+        for k in ("reward", "done", "_obs_buf"):
             v = getattr(self, k)
-            setattr(other, k, None if v is None else v.clone())
+            setattr(other, k, None if v is None else (torch.empty_like(v) if lean else v.clone()))
         return other
 
     __copy__ = clone

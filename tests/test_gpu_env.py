@@ -545,6 +545,15 @@ def test_facade_step_and_expand_entry_points(mod, oracle, cs):
             assert (dense == oh).all()
     assert n_solved >= 1
     assert (env.sim_cube == st[0]).all()
+    for k in (0, 1, 7, 60, 61, 131):                        # whole descents in one launch (60 moves per launch)
+        seq = [int(a) for a in rng.integers(0, A, k)]
+        for a in seq:
+            st, code, done, rew = oracle.step(cs, st, np.array([a], np.uint8))
+        s, r, d, info = env.step_many(seq)
+        assert tree.key_of_state(s) == code[0].tobytes() and d == bool(done[0]) and r == float(rew[0]) and info == {}
+        assert (env.sim_cube == st[0]).all() and (env.cube == s).all()
+    with pytest.raises(IndexError):
+        env.step_many([0, A])
 
 
 def _mp_child(rank, n, steps, seed, q):

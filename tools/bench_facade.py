@@ -56,10 +56,16 @@ def main():
         def predict(self, x):
             return np.float32(-1.0), np.full(12, 1 / 12, np.float32)
     cfg = {"mcts": {"virtual_loss_const": 150, "cpuct": 1.0, "value_min": -10.0}, "test": {"cube_size": 3}}
-    tree = MCTS(M(), cfg)
     env.reset(seed=3, scramble_count=12)
     state = env.cube
-    out["MCTS.train_us_per_simulation"] = per_call(lambda: tree.train(state, env), n=1000, warm=20)
+
+    def search():                                   # test.py:140-142: numMCTSSim = 50 simulations on a fresh tree
+        tree = MCTS(M(), cfg)
+        for _ in range(50):
+            if tree.train(state, env) is not None:
+                break
+    out["MCTS_50_simulations_us"] = per_call(search, n=40, warm=3)
+    out["MCTS_us_per_simulation"] = out["MCTS_50_simulations_us"] / 50
     print(json.dumps({k: round(v, 2) for k, v in out.items()}))
 
 

@@ -14,18 +14,7 @@ using namespace rc;
 using T = Cube3;
 struct Args { const uint8_t *in; uint8_t *out; const uint8_t *act; uint8_t *done; int64_t n, tile; };
 
-template <int V, int AUX> __device__ __forceinline__ Pk<V> bld(__amdgpu_buffer_rsrc_t r, uint32_t lo, uint32_t so) {
-    Pk<V> p;
-    if constexpr (V == 1) p.d[0] = __builtin_amdgcn_raw_buffer_load_b32(r, lo, so, AUX);
-    else if constexpr (V == 2) { u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(r, lo, so, AUX); p.d[0] = u[0]; p.d[1] = u[1]; }
-    else { u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, lo, so, AUX); p.d[0] = u[0]; p.d[1] = u[1]; p.d[2] = u[2]; p.d[3] = u[3]; }
-    return p;
-}
-template <int V, int AUX> __device__ __forceinline__ void bst(__amdgpu_buffer_rsrc_t r, uint32_t lo, uint32_t so, Pk<V> p) {
-    if constexpr (V == 1) __builtin_amdgcn_raw_buffer_store_b32(p.d[0], r, lo, so, AUX);
-    else if constexpr (V == 2) { u32x2 u = {p.d[0], p.d[1]}; __builtin_amdgcn_raw_buffer_store_b64(u, r, lo, so, AUX); }
-    else { u32x4 u = {p.d[0], p.d[1], p.d[2], p.d[3]}; __builtin_amdgcn_raw_buffer_store_b128(u, r, lo, so, AUX); }
-}
+// bld / bst: rc_device.h
 
 template <int V, bool MOVE, int LAUX, int SAUX>
 __global__ void __launch_bounds__(64) k_step_buf(Args a) {
@@ -85,6 +74,39 @@ __global__ void __launch_bounds__(64) k_step_glob(Args a) {
     if constexpr (MOVE) st<V, false>(a.done + g0 + lo, done_bytes(unsolved<T, V>(s)));
 }
 
+
+// The design as literally stated in BASELINE.json's north_star: sticker rows staged in LDS, the move applied as a per-cube
+// BYTE GATHER through a constant-memory permutation table (per-lane divergent action -> vector loads of the table).
+__constant__ PermTable<Cube3> c_perm{};
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_step_table(Args a) {
+    constexpr int TP = BLOCK * 4 + 4;                      // LDS row pitch (bytes), +4 spreads rows over banks
+    __shared__ __attribute__((aligned(16))) uint8_t tile[T::S * TP];
+    const int64_t g0 = (int64_t)blockIdx.x * (BLOCK * 4);
+    const uint32_t lo = threadIdx.x * 4;
+    const int64_t t = g0 / a.tile; const int64_t base = t * T::S * a.tile + (g0 - t * a.tile);
+    { const uint8_t *row = a.in + base;
+#pragma unroll
+      for (int i = 0; i < T::S; ++i) { *reinterpret_cast<uint32_t *>(tile + i * TP + lo) = *reinterpret_cast<const uint32_t *>(row + lo); row += a.tile; } }
+    const uint32_t act = *reinterpret_cast<const uint32_t *>(a.act + g0 + lo);
+    __syncthreads();
+    uint32_t uns = 0, first[6];
+    uint8_t *row = a.out + base;
+#pragma unroll 6
+    for (int i = 0; i < T::S; ++i) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int src = c_perm.v[(act >> (8 * j)) & 0xff][i];
+            o |= (uint32_t)tile[src * TP + lo + j] << (8 * j);
+        }
+        *reinterpret_cast<uint32_t *>(row + lo) = o; row += a.tile;
+        if (i % 9 == 0) first[i / 9] = o; else uns |= o ^ first[i / 9];
+    }
+    Pk<1> u; u.d[0] = uns;
+    *reinterpret_cast<uint32_t *>(a.done + g0 + lo) = done_bytes(u).d[0];
+}
+
 template <class F> double timeit(F &&f, int iters = 30) {
     for (int i = 0; i < 5; i++) f();
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -122,6 +144,24 @@ int main(int argc, char **argv) {
         Args a{buf[0], buf[1], act, done, n, tile}; const int64_t blocks = n / (64 * 4 * V); \
         double t = timeit([&] { a.in = buf[0]; a.out = buf[1]; hipLaunchKernelGGL((k_step_buf<V, MOVE, LA, SA>), dim3(blocks), dim3(64), 0, 0, a); std::swap(buf[0], buf[1]); }); \
         char nm[96]; snprintf(nm, sizeof nm, "%s buffer V%d ld aux %2d st aux %2d", MOVE ? "step" : "copy", V, LA, SA); report(nm, t, MOVE ? 110.0 : 108.0); }
+
+    if (argc > 3 && atoi(argv[3]) == 1) {       // design A/B (run it under rocprofv3 --kernel-trace --stats for the kernel-stat rows)
+        for (int rep = 0; rep < 2; ++rep) {
+            { Args a{buf[0], buf[1], act, done, n, tile}; const int64_t blocks = n / (256 * 4);
+              double t = timeit([&] { a.in = buf[0]; a.out = buf[1]; hipLaunchKernelGGL((k_step_table<256>), dim3(blocks), dim3(256), 0, 0, a); std::swap(buf[0], buf[1]); });
+              report("LITERAL north_star: LDS tile + constant-table byte gather b256", t, 110.0); }
+            { Args a{buf[0], buf[1], act, done, n, tile}; const int64_t blocks = n / (64 * 4);
+              double t = timeit([&] { a.in = buf[0]; a.out = buf[1]; hipLaunchKernelGGL((k_step_table<64>), dim3(blocks), dim3(64), 0, 0, a); std::swap(buf[0], buf[1]); });
+              report("LITERAL north_star: LDS tile + constant-table byte gather b64", t, 110.0); }
+            RUNG(2, true, true, "round-1 shipped: packed select network, global nt V2");
+            RUNB(2, true, 2, 17);
+            RUNG(2, false, true, "row-structured copy of the same buffers (global nt V2)");
+            RUNB(2, false, 2, 17);
+            { double t = timeit([&] { CK(hipMemcpyAsync(buf[1], buf[0], 54 * n, hipMemcpyDeviceToDevice, 0)); std::swap(buf[0], buf[1]); });
+              report("hipMemcpyAsync D2D", t, 108.0); }
+        }
+        return 0;
+    }
     for (int rep = 0; rep < 2; ++rep) {
         RUNG(2, true, true, "step global V2 nt (shipped form)");
         RUNG(2, true, false, "step global V2 cached");

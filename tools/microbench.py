@@ -86,9 +86,9 @@ def main():
             t = timeit(lambda: ops.apply_moves(a, b, acts, m, 3, None, done, oh, fmt), iters=10)
             out.append(dict(k=f"step_dense_{name}_1M", ms=t * 1e3, Gsteps=m / t / 1e9, GBps=(110 + bpc) * m / t / 1e9))
             del oh
-    if "adi" in which:
+    if "adi" in which or "adiplain" in which:
         W, D = 100_000, 30
-        for pitch in (None, ops.ADI_TILE):
+        for pitch in ((ops.ADI_TILE,) if "adi" in which else (None,)):       # "adi": the default tiling only (fresh-process repeats)
             tag = "plain" if pitch is None else f"tile{pitch}"
             pt, bufs = ops.adi_buffers(W, D, 3, "cuda", pitch or _lib.pitch_for(W), parents=True, children=True)
             t = timeit(lambda: ops.adi_generate(W, D, 3, pt, "cuda", seed=2024, **bufs), iters=5, warm=2)

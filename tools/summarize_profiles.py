@@ -1,11 +1,18 @@
 #!/usr/bin/env python3
-"""Copy the rocprofv3 summaries of one gpu_round.sh run from gpurun_out/ into profiles/ (tracked).
+"""Copy the rocprofv3 summaries of one tools/gpu_round.sh run from gpurun_out/ (scratch) into profiles/ (tracked).
 
-    python tools/summarize_profiles.py r01a r01      # <gpurun tag> <round name>
-Writes profiles/<round>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), <round>_pmc.json (mean
-FETCH_SIZE / WRITE_SIZE per kernel, separate passes) and refreshes profiles/traffic.json, which bench.py
-reads for roofline.traffic.  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 wide
-coalesced streaming reads (it tallies 128-B requests at 64 B); WRITE_SIZE is exact; both are in KiB."""
+    python tools/summarize_profiles.py r02a r02      # <gpurun tag> <round name>
+
+Writes
+  profiles/<round>_bench.json               the bench.py JSON line of the session
+  profiles/<round>_kernel_stats.csv         rocprofv3 --kernel-trace --stats of `python3 bench.py --no-cpu --steps 200 --warmup 20`
+  profiles/<round>_pmc.json                 mean FETCH_SIZE / WRITE_SIZE / SQ counters per kernel (separate --pmc passes)
+  profiles/<round>_adi_fresh_processes.json k_adi / k_expand averages of FIVE fresh processes (rocprofv3 kernel stats each)
+  profiles/<round>_design_kernel_stats.csv  kernel-stat rows of the design A/B harness (tools/exp/exp_step2 22 0 1)
+  profiles/<round>_{cfg5,rollout,facade,adi_pipeline}.json   tool outputs of the same session
+  profiles/traffic.json                     HBM-side bytes per k_step launch, read by bench.py for roofline.traffic
+FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 wide coalesced streaming reads (it tallies
+128-B requests at 64 B); WRITE_SIZE is exact; both are in KiB."""
 import collections
 import csv
 import glob
@@ -19,29 +26,75 @@ tag, rnd = sys.argv[1], sys.argv[2]
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
-stats = glob.glob(os.path.join(G, f"{tag}_prof_stats", "**", "*_kernel_stats.csv"), recursive=True)
+
+
+def short(k):
+    return k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:90]
+
+
+def first(pattern):
+    f = glob.glob(os.path.join(G, pattern), recursive=True)
+    return f[0] if f else None
+
+
+for name in ("bench", "cfg5", "rollout", "facade", "adi_pipeline"):
+    src = os.path.join(G, f"{tag}_{name}.json")
+    if os.path.exists(src) and os.path.getsize(src):
+        lines = [l for l in open(src).read().splitlines() if l.startswith("{")]
+        if lines:
+            json.dump(json.loads(lines[-1]), open(os.path.join(P, f"{rnd}_{name}.json"), "w"), indent=1)
+
+stats = first(f"{tag}_prof_stats/**/*_kernel_stats.csv")
 if stats:
-    shutil.copy(stats[0], os.path.join(P, f"{rnd}_kernel_stats.csv"))
-micro = glob.glob(os.path.join(G, f"{tag}_prof_micro", "**", "*_kernel_stats.csv"), recursive=True)
-if micro:
-    shutil.copy(micro[0], os.path.join(P, f"{rnd}_kernel_stats_microbench.csv"))
+    shutil.copy(stats, os.path.join(P, f"{rnd}_kernel_stats.csv"))
+design = first(f"{tag}_prof_design/**/*_kernel_stats.csv")
+if design:
+    shutil.copy(design, os.path.join(P, f"{rnd}_design_kernel_stats.csv"))
+
+fresh = []
+for i in range(1, 6):
+    f = first(f"{tag}_prof_adi{i}/**/*_kernel_stats.csv")
+    if not f:
+        continue
+    row = {"process": i}
+    for r in csv.DictReader(open(f)):
+        k = short(r["Name"])
+        if k.startswith(("k_adi<", "k_expand<")):
+            row[k] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3}
+    fresh.append(row)
+if fresh:
+    W, D = 100_000, 30
+    key = "k_adi<rc::Cube3, 2, false>"
+    avgs = [r[key]["avg_us"] for r in fresh if key in r]
+    json.dump({"command": "rocprofv3 --kernel-trace --stats -- python3 tools/microbench.py adi expand   (x5, a fresh process each)",
+               "workload": "k_adi: 100000 walks x depth 30, parents + 12 children + flags + actions, default dispatch and tiling; "
+                           "k_expand<..., 2, false>: 2^20 parents, 3 output tilings",
+               "algorithmic_bytes_per_launch_k_adi": 715 * W * D,
+               "k_adi_avg_us_per_process": avgs,
+               "k_adi_GBps_per_process": [715 * W * D / (a * 1e-6) / 1e9 for a in avgs],
+               "k_adi_frac_of_8TBps_per_process": [715 * W * D / (a * 1e-6) / 8e12 for a in avgs],
+               "processes": fresh}, open(os.path.join(P, f"{rnd}_adi_fresh_processes.json"), "w"), indent=1)
+
 pmc = {}
-for name in ("fetch", "write", "sq", "microwrite"):
+for name in ("fetch", "write", "sq"):
     for f in glob.glob(os.path.join(G, f"{tag}_prof_{name}", "**", "*_counter_collection.csv"), recursive=True):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             agg[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (k, c), v in agg.items():
-            short = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:80]
-            pmc.setdefault(short, {})[c] = {"mean": sum(v) / len(v), "launches": len(v)}
-json.dump(pmc, open(os.path.join(P, f"{rnd}_pmc.json"), "w"), indent=1, sort_keys=True)
-step = [v for k, v in pmc.items() if k.startswith("k_step<rc::Cube3") and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
+            pmc.setdefault(short(k), {})[c] = {"mean": sum(v) / len(v), "launches": len(v)}
+pmc = {k: v for k, v in pmc.items() if k.startswith("k_")}          # our kernels only (torch's GEMMs etc. are not the subject)
+if pmc:
+    json.dump(pmc, open(os.path.join(P, f"{rnd}_pmc.json"), "w"), indent=1, sort_keys=True)
+step = [(k, v) for k, v in pmc.items() if k.startswith("k_step<rc::Cube3, 2, true, true, false, 1") and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
 if step:
-    s = max(step, key=lambda v: v["FETCH_SIZE"]["launches"])
+    k, s = max(step, key=lambda kv: kv[1]["FETCH_SIZE"]["launches"])
     rd, wr = s["FETCH_SIZE"]["mean"] * 1024 * 2, s["WRITE_SIZE"]["mean"] * 1024
-    json.dump({"round": rnd, "k_step_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
+    json.dump({"round": rnd, "kernel": k, "k_step_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
                "note": "FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE KiB x 1024, separate --pmc passes, "
-                       "bench.py workload (2^22 cubes, move + done flag); algorithmic = 110 B x 2^22 = 461373440"},
+                       "bench.py workload (2^22 cubes, move + done flag); algorithmic = 110 B x 2^22 = 461373440.  These are the L2's "
+                       "fabric-side request counters: Infinity-Cache hits are counted, so this is fabric traffic, an upper bound of DRAM traffic"},
               open(os.path.join(P, "traffic.json"), "w"), indent=1)
-print(open(os.path.join(P, f"{rnd}_kernel_stats.csv")).read()[:1500] if stats else "no stats")
-print(json.dumps(pmc, indent=1)[:1500])
+for k in sorted(pmc):
+    print(k, {c: round(v["mean"], 1) for c, v in pmc[k].items() if c in ("FETCH_SIZE", "WRITE_SIZE")})
+print(open(os.path.join(P, f"{rnd}_kernel_stats.csv")).read()[:600] if stats else "no stats")

@@ -520,8 +520,56 @@ __device__ __forceinline__ uint32_t onehot_bits4(const uint8_t *lds_code, int tp
     }
 }
 
+// 3x3x3 fast path (256-thread workgroups): a cube is 480 elements = 120 / 60 / 30 sixteen-byte chunks (f32 / 16-bit / u8), so
+// 240 threads cover exactly 2 / 4 / 8 whole cubes per pass and thread t ALWAYS writes the same chunk of a cube: its one-hot
+// row(s) and columns are fixed before the loop, a pass costs one LDS byte read, a few compares and one 16-byte store
+// (the generic loop below re-derives cube / row / column from the element index with two divisions per store).
+template <class T, class E>
+__device__ __forceinline__ void dense_write_333(const uint8_t *lds_code, int tp, E *out, int ncubes, int tid) {
+    static_assert(T::SIZE == 3 && T::R * T::C == 480 && T::C % 4 == 0);
+    constexpr int EPT = 16 / (int)sizeof(E), CPC = 480 / EPT, CPP = 240 / CPC;   // elements per chunk, chunks per cube, cubes per pass
+    if (tid >= 240) return;
+    const int sub = tid / CPC, k = tid - sub * CPC;
+    const __amdgpu_buffer_rsrc_t srd = make_srd(out);                           // `out` is workgroup-uniform
+    uint32_t off = (uint32_t)sub * 480u * (uint32_t)sizeof(E) + (uint32_t)k * 16u;
+    if constexpr (sizeof(E) >= 2) {                                              // the whole chunk lies in one row (24 % EPT == 0)
+        const int e0 = k * EPT, r = e0 / T::C;
+        const uint32_t c0 = (uint32_t)(e0 - r * T::C);
+        const uint8_t *src = lds_code + r * tp;
+        for (int cube = sub; cube < ncubes; cube += CPP, off += CPP * 480u * (uint32_t)sizeof(E)) {
+            const uint32_t d = (uint32_t)src[cube] - c0;                         // which element of the chunk is the 1 (if < EPT)
+            Pk<4> u;
+            if constexpr (sizeof(E) == 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) u.d[j] = d == (uint32_t)j ? One<E>::v : 0u;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) u.d[j] = (d == (uint32_t)(2 * j) ? One<E>::v : 0u) | (d == (uint32_t)(2 * j + 1) ? One<E>::v << 16 : 0u);
+            }
+            bst<4, kAuxStreamStore>(srd, off, 0, u);
+        }
+    } else {                                                                     // u8: 16 elements may straddle two rows; per dword (4 elements, one row)
+        int rr[4];
+        uint32_t cc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int e = k * 16 + 4 * j; rr[j] = e / T::C; cc[j] = (uint32_t)(e - rr[j] * T::C); }
+        for (int cube = sub; cube < ncubes; cube += CPP, off += CPP * 480u) {
+            Pk<4> u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t d = (uint32_t)lds_code[rr[j] * tp + cube] - cc[j];
+                u.d[j] = d < 4u ? 1u << (8u * d) : 0u;
+            }
+            bst<4, kAuxStreamStore>(srd, off, 0, u);
+        }
+    }
+}
+
 template <class T, class E>
 __device__ __forceinline__ void dense_write(const uint8_t *lds_code, int tp, E *out, int ncubes, int tid, int nthreads) {
+    if constexpr (T::SIZE == 3) {
+        if (nthreads == 256) { dense_write_333<T, E>(lds_code, tp, out, ncubes, tid); return; }
+    }
     constexpr int EPT = 16 / (int)sizeof(E);  // elements per 16-byte store
     const uint32_t total = (uint32_t)ncubes * T::R * T::C;
     const uint32_t chunks = (total + EPT - 1) / EPT;

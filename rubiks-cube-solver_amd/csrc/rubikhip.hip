@@ -1147,7 +1147,7 @@ int rc_read_status(uint32_t *status, void *stream) {
     // one atomic read-and-clear on the device (bits set by kernels still running on OTHER streams are neither lost nor
     // reported early: they show in a later read); the word travels through a pinned, host-mapped scratch word
     static thread_local uint32_t *host_word = nullptr;
-    if (!host_word) RC_HIP(hipHostMalloc(reinterpret_cast<void **>(&host_word), sizeof(uint32_t), hipHostMallocMapped));
+    if (!host_word) RC_HIP(hipHostMalloc(reinterpret_cast<void **>(&host_word), sizeof(uint32_t), hipHostMallocMapped | hipHostMallocPortable));
     *host_word = 0xffffffffu;
     hipLaunchKernelGGL(k_read_status, dim3(1), dim3(1), 0, S(stream), host_word);
     RC_HIP(hipGetLastError());

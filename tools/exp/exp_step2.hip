@@ -162,6 +162,15 @@ int main(int argc, char **argv) {
         }
         return 0;
     }
+
+    if (argc > 3 && atoi(argv[3]) == 2) {       // finer policy sweep around the round-2 choice (ld nt, st sc0 sc1)
+        for (int rep = 0; rep < 2; ++rep) {
+            RUNB(2, true, 2, 17); RUNB(2, true, 2, 16); RUNB(2, true, 2, 1); RUNB(2, true, 2, 0);
+            RUNB(2, true, 3, 17); RUNB(2, true, 18, 17); RUNB(2, true, 19, 17); RUNB(2, true, 3, 16); RUNB(2, true, 18, 16);
+            RUNB(4, true, 2, 17); RUNB(4, true, 2, 16); RUNB(1, true, 2, 17);
+        }
+        return 0;
+    }
     for (int rep = 0; rep < 2; ++rep) {
         RUNG(2, true, true, "step global V2 nt (shipped form)");
         RUNG(2, true, false, "step global V2 cached");

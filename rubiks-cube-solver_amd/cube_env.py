@@ -88,13 +88,21 @@ class CubeEnv:
 
     def reset(self, seed=None, scramble_count=2):
         """Reset to a randomly scrambled cube (cube_env.py:50-69): the global legacy numpy RNG is
-        saved, optionally seeded, used for `randint(action_dim, size=scramble_count)` and restored."""
-        self.init_state()
+        saved, optionally seeded, used for `randint(action_dim, size=scramble_count)` and restored.
+        Device work: one fill launch + one rc_facade_steps launch for the whole scramble."""
         origin_state = np.random.get_state()
         if seed is not None:
             np.random.seed(seed)
         action_sequence = np.random.randint(self.action_dim, size=scramble_count)
         np.random.set_state(origin_state)
+        if hasattr(self._vec, "stickers"):
+            ops.fill_solved(self._vec.stickers, 1, self.cube_size)
+            self._sim_cache = None
+            if len(action_sequence) == 0:
+                self._cube_cache = None
+                raise UnboundLocalError("local variable 'state' referenced before assignment")  # cube_env.py:69
+            return self.step_many([int(a) for a in action_sequence])[0]
+        self.init_state()
         if len(action_sequence) == 0:
             raise UnboundLocalError("local variable 'state' referenced before assignment")  # cube_env.py:69
         obs = self._vec.reset(actions=action_sequence.reshape(1, -1).astype(np.uint8), scramble_count=len(action_sequence))

@@ -200,3 +200,18 @@ def test_step_policies_agree_at_scale(ops, L, cs):
         assert torch.equal(ops.to_aos(out, n), valid), variant
         assert torch.equal(done, ref_done), variant
     assert L.read_status() == 0
+
+
+def test_adi_codes_default_dispatch_100k(ops, L, oracle):
+    """The code-only ADI instantiation at config 3's walk count (default dispatch: narrow packs, two parts): parent and
+    child codes, flags and actions of 100 000 walks x depth 4 against the oracle."""
+    cs, W, D = 3, 100_000, 4
+    pt, bufs = ops.adi_buffers(W, D, cs, "cuda", parents=True, parent_code=True, child_code=True)
+    ops.adi_generate(W, D, cs, pt, "cuda", seed=5, stream_id=1, **bufs)
+    exp = oracle.adi(cs, W, D, seed=5, stream=1, threads=oracle.max_threads(), want_children=False)
+    assert (bufs["actions_out"][:, :W].cpu().numpy().T == exp["actions"]).all()
+    assert (untile(ops, bufs["parents"], W, 1).transpose(1, 0, 2) == exp["parents"]).all()
+    assert (untile(ops, bufs["parent_code"], W, 1).transpose(1, 0, 2) == exp["parent_code"]).all()
+    assert (untile(ops, bufs["child_code"], W, 2).transpose(2, 0, 1, 3) == exp["child_code"]).all()
+    assert (bufs["child_solved"][..., :W].cpu().numpy().transpose(2, 0, 1) == exp["child_solved"]).all()
+    assert L.read_status() == 0

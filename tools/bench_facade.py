@@ -30,6 +30,8 @@ def main():
     acts = np.random.default_rng(0).integers(0, 12, 100000)
     it = iter(acts)
     out["CubeEnv.step_us"] = per_call(lambda: env.step(int(next(it))))
+    seeds = iter(range(10 ** 6))
+    out["CubeEnv.reset_seed_k30_us"] = per_call(lambda: env.reset(seed=next(seeds), scramble_count=30), n=2000)
     f = env._facade()
     sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     seq = [f[5]]

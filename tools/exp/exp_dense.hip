@@ -103,6 +103,8 @@ int main() {
 #define RUNW(TILE, AUX, GRID) { const int64_t tiles = (n + TILE - 1) / TILE; const int64_t g = std::min<int64_t>(tiles, GRID); \
         double t = timeit([&] { hipLaunchKernelGGL((k_dense_wave<TILE, AUX>), dim3(g), dim3(64), 0, 0, code, n, pitch, out); }); \
         printf("wave tile %4d           aux %2d grid %6lld: %7.1f us %7.1f GB/s\n", TILE, AUX, (long long)g, t * 1e6, bytes / t / 1e9); fflush(stdout); }
+        RUN(8, true, 19, 256); RUN(16, true, 19, 256); RUN(32, true, 19, 256); RUN(64, true, 19, 256); RUN(16, true, 0, 256); RUN(16, true, 2, 256); RUN(16, true, 17, 256);
+        RUN(16, true, 19, 1024); RUN(32, true, 19, 1024); RUN(64, true, 19, 512);
         RUN(256, false, 19, 0); RUN(256, true, 19, 2048);
         RUN(64, false, 19, 0); RUN(32, false, 19, 0); RUN(16, false, 19, 0); RUN(8, false, 19, 0);
         RUN(16, true, 19, 2048); RUN(16, true, 19, 512); RUN(8, true, 19, 2048);

@@ -125,5 +125,20 @@ out["adi_and_expand_real_kernels"] = {
     "reading": "16 walks per lane is the best store shape but one wave per 1024 walks cannot hide the walk's VALU work (0.44 ms); 8 walks per lane, "
                "one wave per group, 16384-walk tiles: 0.32 ms = 6.7 TB/s for 100k x 30 (round 1: 0.35-0.43 ms); 1M-parent expansion 117 us = 6.4 TB/s (round 1: 136 us)",
 }
+# ---- 5. dense f32 one-hot writers: shape x buffer placement
+dense = collections.OrderedDict()
+for name in ("r02_expd.log", "r02_expd2.log"):
+    for l in lines(name):
+        m = re.match(r"(.*?):\s+([\d.]+) us", l)
+        if m:
+            dense.setdefault(name, collections.OrderedDict()).setdefault(m.group(1).strip(), []).append(float(m.group(2)))
+out["dense_one_hot_writers"] = {
+    "what": "compact code [20][N] -> dense f32 one-hot [N][20][24] for 2^20 cubes (2.013 GB written), four separately allocated output buffers per process",
+    "harness": "tools/exp/exp_dense.hip: `wg` = 256-thread workgroup per tile of TILE cubes through an LDS code tile (persist 1 = grid-stride with the given grid), "
+               "`wave` = one wave per tile reading codes from global; aux = cache bits of the 16-byte stores; tools/exp/dense_place.py probes offsets inside one pool",
+    "us_per_placement": dense,
+    "reading": "every many-stream writer is bimodal between allocations (about 310 vs 375 us); hipMemsetAsync is not (296-308 us); one-workgroup-per-CU sweeps are "
+               "immune too but stop at 345-355 us; the shipped 256-cube-tile form is fastest on good placements and within 3 % of the best on bad ones",
+}
 json.dump(out, open(os.path.join(ROOT, "profiles", "r02_design_ab.json"), "w"), indent=1)
 print("wrote profiles/r02_design_ab.json:", {k: (len(v.get("rows", [])) if isinstance(v, dict) else None) for k, v in out.items() if isinstance(v, dict)})

@@ -16,7 +16,7 @@ int main(void) {
     const int64_t n = 5, pitch = 256;
     uint8_t *st, *act, *done, host[54 * 256], hdone[8], hact[16];
     float *reward, hrew[8];
-    if (rc_version() < 100) return 1;
+    if (rc_version() < 200) return 1;
     RC(rc_init(0));
     CK(hipMalloc((void **)&st, 54 * pitch)); CK(hipMalloc((void **)&act, 16)); CK(hipMalloc((void **)&done, 16));
     CK(hipMalloc((void **)&reward, 16 * sizeof(float)));
@@ -43,9 +43,29 @@ int main(void) {
     RC(rc_apply_moves(st, st, act, n, pitch, pitch, 3, reward, done, NULL, RC_FMT_NONE, 0, NULL));
     CK(hipMemcpy(hrew, reward, sizeof hrew, hipMemcpyDeviceToHost)); CK(hipMemcpy(hdone, done, 8, hipMemcpyDeviceToHost));
     if (hrew[2] != 1.0f || hdone[2] != 1) return 7;
+    /* the batch-1 latency path: results arrive in host-mapped pinned memory, no copies, no stream sync */
+    uint8_t *pinned;
+    CK(hipHostMalloc((void **)&pinned, 8192, hipHostMallocMapped));
+    memset(pinned, 0, 8192);
+    RC(rc_fill_solved(st, n, pitch, 3, NULL));
+    for (int k = 0; k < 4; ++k) RC(rc_facade_step(st, pitch, 3, seq[k], pinned, (uint32_t)(k + 1), 1, NULL));
+    const uint8_t kat_cols[20] = {9, 3, 20, 1, 12, 15, 7, 21, 6, 2, 4, 18, 8, 10, 12, 14, 16, 0, 20, 22};   /* SURVEY 8c KAT-A */
+    for (int r = 0; r < 20; ++r)
+        for (int c = 0; c < 24; ++c)
+            if (pinned[r * 24 + c] != (c == kat_cols[r])) { fprintf(stderr, "facade one-hot mismatch row %d col %d\n", r, c); return 10; }
+    if (pinned[496] != 0) return 11;
+    const uint8_t undo[4] = {0, 4, 1, 5};                      /* U R U' R' = (R U R' U')^-1: one launch */
+    RC(rc_facade_steps(st, pitch, 3, undo, 4, pinned, 9u, 1, NULL));
+    if (pinned[496] != 1) return 12;
+    RC(rc_facade_expand(st, pitch, 3, pinned, 10u, 1, 1, NULL));
+    for (int a = 0; a < 12; ++a) if (pinned[288 + a] != 0) return 13;      /* no child of the solved cube is solved */
+    /* per-call tuning override instead of any global knob */
+    RC(rc_apply_moves_ex(st, st, act, n, pitch, pitch, 3, reward, done, NULL, RC_FMT_NONE, 0, NULL, 21));
+    CK(hipHostFree(pinned));
     uint32_t status = 99;
     RC(rc_read_status(&status, NULL));
     if (status != 0) return 8;
+    if (rc_fill_solved(st, 1, (int64_t)1 << 27, 3, NULL) != RC_EINVAL) return 14;   /* rows * pitch must stay below 2^32 */
     if (rc_fill_solved(NULL, 1, 256, 3, NULL) != RC_EINVAL || strlen(rc_last_error()) == 0) return 9;
     puts("abi_smoke ok");
     return 0;

@@ -377,6 +377,8 @@ def test_argument_errors(ops, L):
     assert b"rc_fill_solved" in L.lib().rc_last_error()
     assert L.lib().rc_fill_solved(L.ptr(st), 1, 256, 5, None) == -1
     assert L.lib().rc_fill_solved(L.ptr(st), 2000, 48, 3, None) == -1
+    assert L.lib().rc_fill_solved(L.ptr(st), 1, 1 << 27, 3, None) == -1      # rows * pitch >= 2^32: single tiles stop at ~79 M cubes
+    assert L.lib().rc_facade_step(L.ptr(st), 256, 3, 0, None, 1, 1, None) == -1 and b"rc_facade_step" in L.lib().rc_last_error()
 
 
 @pytest.mark.parametrize("cs", CS)

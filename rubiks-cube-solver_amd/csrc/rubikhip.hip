@@ -1087,11 +1087,25 @@ int rc_adi_targets(const float *child_value, const uint8_t *child_solved, const 
 
 static int facade_wait(uint8_t *host_out, uint32_t seq, void *stream, const char *who);
 
+// host_out is dereferenced by the HOST while polling: it must be host (pinned) memory.  Checked once per buffer and thread.
+static int facade_check_host(const uint8_t *host_out, const char *who) {
+    static thread_local const uint8_t *checked = nullptr;
+    if (host_out == checked) return RC_OK;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, host_out) != hipSuccess || attr.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();
+        return fail(RC_EINVAL, "%s: host_out must be host-mapped pinned memory (hipHostMalloc / torch pin_memory)", who);
+    }
+    checked = host_out;
+    return RC_OK;
+}
+
 int rc_facade_steps(uint8_t *stp, int64_t pitch, int cube_size, const uint8_t *actions, int n_actions, uint8_t *host_out, uint32_t seq,
                     int wait, void *stream) {
     if (!stp || !host_out || pitch <= 0 || pitch * 54 >= ((int64_t)1 << 32)) return fail(RC_EINVAL, "rc_facade_steps: bad arguments%s");
     if (n_actions < 0 || (n_actions > 0 && !actions)) return fail(RC_EINVAL, "rc_facade_steps: bad action list%s");
     if (seq == 0) return fail(RC_EINVAL, "rc_facade_steps: seq must be non-zero%s");
+    if (int rc = facade_check_host(host_out, "rc_facade_steps")) return rc;
     const int rc = by_size(cube_size, [&](auto t) {
         using T = decltype(t);
         int done = 0;
@@ -1132,6 +1146,7 @@ static int facade_wait(uint8_t *host_out, uint32_t seq, void *stream, const char
 int rc_facade_expand(const uint8_t *stp, int64_t pitch, int cube_size, uint8_t *host_out, uint32_t seq, int dense, int wait, void *stream) {
     if (!stp || !host_out || pitch <= 0 || pitch * 54 >= ((int64_t)1 << 32)) return fail(RC_EINVAL, "rc_facade_expand: bad arguments%s");
     if (seq == 0) return fail(RC_EINVAL, "rc_facade_expand: seq must be non-zero%s");
+    if (int rc = facade_check_host(host_out, "rc_facade_expand")) return rc;
     const int rc = by_size(cube_size, [&](auto t) {
         using T = decltype(t);
         hipLaunchKernelGGL((k_facade_expand<T>), dim3(1), dim3(kWave), 0, S(stream), stp, (uint32_t)pitch, host_out, seq, dense);

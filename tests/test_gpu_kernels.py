@@ -379,6 +379,8 @@ def test_argument_errors(ops, L):
     assert L.lib().rc_fill_solved(L.ptr(st), 2000, 48, 3, None) == -1
     assert L.lib().rc_fill_solved(L.ptr(st), 1, 1 << 27, 3, None) == -1      # rows * pitch >= 2^32: single tiles stop at ~79 M cubes
     assert L.lib().rc_facade_step(L.ptr(st), 256, 3, 0, None, 1, 1, None) == -1 and b"rc_facade_step" in L.lib().rc_last_error()
+    dev_buf = torch.zeros(8192, dtype=torch.uint8, device="cuda")             # the result buffer must be HOST memory: refused, not a crash
+    assert L.lib().rc_facade_step(L.ptr(st), 256, 3, 0, L.ptr(dev_buf), 1, 1, None) == -1 and b"pinned" in L.lib().rc_last_error()
 
 
 @pytest.mark.parametrize("cs", CS)

@@ -558,61 +558,93 @@ struct FacadeActs {
     uint8_t a[kFacadeMaxActs];
 };
 
+// One cube is latency, not throughput: these two kernels run the reference's algorithm LITERALLY, one lane per sticker
+// (doMove_3 = a gather through the permutation table, py333.py:220-222; isSolved_3, :229-233) and one lane per piece slot
+// (getOP_3's hash + table look-up, :224-227), with wave shuffles (ds_bpermute) as the gather.  ~150 instructions per lane
+// and two dependent memory round trips instead of the packed network's ~1400 serial VALU instructions for a single cube.
 template <class T>
-__global__ void __launch_bounds__(kWave) k_facade_step(uint8_t *st, uint32_t pitch, FacadeActs acts, uint8_t *host_out, uint32_t seq) {
-    __shared__ uint8_t code_lds[32];
-    const int lane = threadIdx.x;
-    Pk<1> o[T::S];
-#pragma unroll
-    for (int i = 0; i < T::S; ++i) o[i].d[0] = st[i * pitch];             // cube 0 only; uniform loads
-    for (uint32_t k = 0; k < acts.n; ++k) {                               // the moves of one tree descent, in one launch
-        Pk<1> act;
-        act.d[0] = acts.a[k];                                             // bytes 1..3 (pad cubes): action 0
-        Pk<1> m[T::A];
-        const Pk<1> bad = action_masks<T, 1>(act, m);
-        if (bad.d[0] & 0xffu) atomicOr(&g_status, RC_STATUS_BAD_ACTION);
-        Pk<1> s[T::S];
-#pragma unroll
-        for (int i = 0; i < T::S; ++i) s[i] = o[i];
-        apply_move<T, 1>(s, m, o);
+struct FacadeTables {
+    uint8_t perm[T::A][64];            // perm[a][lane]: source lane of sticker `lane` under action a (lanes >= S: themselves)
+    uint8_t slot[32][4];               // sticker indices of piece slot p (corner: 3, edge: 2), [3] = 1 for corners
+    uint8_t child[T::A * T::SLOTS][4]; // the same for slot p of child a, as PARENT sticker indices: perm[a][slot[p][k]]
+    constexpr FacadeTables() : perm{}, slot{}, child{} {
+        for (int a = 0; a < T::A; ++a)
+            for (int i = 0; i < 64; ++i) perm[a][i] = (uint8_t)(i < T::S ? kPerm<T>.v[a][i] : i);
+        for (int p = 0; p < T::SLOTS; ++p) {
+            if (p < T::NC) { slot[p][0] = T::cdef[p][0]; slot[p][1] = T::cdef[p][1]; slot[p][2] = T::cdef[p][2]; slot[p][3] = 1; }
+            else { slot[p][0] = T::edef[p - T::NC][0]; slot[p][1] = T::edef[p - T::NC][1]; slot[p][2] = 0; slot[p][3] = 0; }
+        }
+        for (int a = 0; a < T::A; ++a)
+            for (int p = 0; p < T::SLOTS; ++p) {
+                for (int k = 0; k < 3; ++k) child[a * T::SLOTS + p][k] = kPerm<T>.v[a][slot[p][k]];
+                child[a * T::SLOTS + p][3] = slot[p][3];
+            }
     }
-    if (lane < T::S) {
-        // lane i stores sticker i: a run-time register index is avoided by a compile-time select chain
-        uint32_t v = 0;
-        sfor<T::S>([&](auto ic) { constexpr int i = decltype(ic)::value; if (lane == i) v = o[i].d[0]; });
-        st[lane * pitch] = (uint8_t)v;
-    }
-    if (seq == 0) return;                                                 // an intermediate launch of a long path: state only
-    const Pk<1> dn = done_bytes(unsolved<T, 1>(o));
-    Pk<1> c[T::SLOTS];
-    encode<T, 1>(o, c);
-    if (lane == 0) {
-#pragma unroll
-        for (int p = 0; p < T::SLOTS; ++p) code_lds[p] = (uint8_t)c[p].d[0];
-    }
-    __syncthreads();
+};
+__constant__ FacadeTables<Cube3> c_facade3{};
+__constant__ FacadeTables<Cube2> c_facade2{};
+template <class T> __device__ __forceinline__ const FacadeTables<T> &facade_tables();
+template <> __device__ __forceinline__ const FacadeTables<Cube3> &facade_tables<Cube3>() { return c_facade3; }
+template <> __device__ __forceinline__ const FacadeTables<Cube2> &facade_tables<Cube2>() { return c_facade2; }
+
+// code of one piece slot from its three (two) sticker colours: hash + the 72-byte LUT held in literals (lut72)
+template <class T>
+__device__ __forceinline__ uint32_t slot_code(uint32_t c0, uint32_t c1, uint32_t c2, bool corner) {
+    Pk<1> hc, he;
+    hc.d[0] = c0 + 2u * c1 + 10u * c2;                                   // py333.py:167,225
+    he.d[0] = c0 + 10u * c1;                                              // py333.py:168,226
+    const uint32_t cc = lut72<T, 1, true>(hc).d[0] & 0xffu;
+    if constexpr (T::NE == 0) return cc;
+    else return corner ? cc : (lut72<T, 1, false>(he).d[0] & 0xffu);
+}
+
+// lane l writes bytes 8l .. 8l+7 of one dense uint8 one-hot [R][C]; `code` holds slot p's code in lane p
+template <class T>
+__device__ __forceinline__ void facade_write_onehot(uint32_t code, uint8_t *out, int lane) {
     constexpr int RC_ = T::R * T::C;
-    if (lane * 8 < RC_) {
-        uint32_t w[2] = {0u, 0u};
+    const int e0 = lane * 8;
+    uint32_t w[2] = {0u, 0u};
+    if constexpr (T::SIZE == 3) {                                         // row = slot, column = code; 8 | 24: one row per lane
+        const int r = e0 < RC_ ? e0 / T::C : 0;
+        const uint32_t d = (uint32_t)__shfl((int)code, r) - (uint32_t)(e0 - r * T::C);
+        if (d < 8u) w[d >> 2] = 1u << (8u * (d & 3u));
+    } else {                                                              // row = piece, column = slot*3 + ori (cube_env.py:143-147)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int e = lane * 8 + j;
-            if (e < RC_) {
-                const int r = e / T::C, col = e - r * T::C;
-                bool one;
-                if constexpr (T::SIZE == 3) one = code_lds[r] == col;                      // row = slot, column = code
-                else { const int slot = col / 3, ori = col - slot * 3; one = code_lds[slot] == r * 3 + ori; }   // row = piece (cube_env.py:143-147)
-                if (one) w[j >> 2] |= 1u << (8 * (j & 3));
-            }
-        }
-        if (lane * 8 + 8 <= RC_) {
-            u32x2 u = {w[0], w[1]};
-            *reinterpret_cast<u32x2 *>(host_out + lane * 8) = u;
-        } else {
-            for (int j = 0; lane * 8 + j < RC_; ++j) host_out[lane * 8 + j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+            const int e = e0 + j < RC_ ? e0 + j : 0;
+            const int r = e / T::C, col = e - r * T::C, sl = col / 3, ori = col - sl * 3;
+            const uint32_t cs = (uint32_t)__shfl((int)code, sl);
+            if (e0 + j < RC_ && cs == (uint32_t)(r * 3 + ori)) w[j >> 2] |= 1u << (8 * (j & 3));
         }
     }
-    if (lane == 0) host_out[kFacadeDone] = (uint8_t)(dn.d[0] & 1u);
+    if (e0 + 8 <= RC_) {
+        u32x2 u = {w[0], w[1]};
+        *reinterpret_cast<u32x2 *>(out + e0) = u;
+    } else {
+        for (int j = 0; e0 + j < RC_; ++j) out[e0 + j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+    }
+}
+
+template <class T>
+__global__ void __launch_bounds__(kWave) k_facade_step(uint8_t *st, uint32_t pitch, FacadeActs acts, uint8_t *host_out, uint32_t seq) {
+    const FacadeTables<T> &tb = facade_tables<T>();
+    const int lane = threadIdx.x;
+    const int i = lane < T::S ? lane : 0;
+    uint32_t v = st[(uint32_t)i * pitch];                                 // lane i = sticker i of cube 0
+    for (uint32_t k = 0; k < acts.n; ++k) {                               // the moves of one tree descent, in one launch
+        const uint32_t a = acts.a[k];                                     // wave-uniform
+        if (a < (uint32_t)T::A) v = (uint32_t)__shfl((int)v, tb.perm[a][lane]);   // new[i] = old[moveDefs[a][i]]
+        else if (a != (uint32_t)T::A && lane == 0) atomicOr(&g_status, RC_STATUS_BAD_ACTION);   // A itself is the no-op
+    }
+    if (lane < T::S) st[(uint32_t)lane * pitch] = (uint8_t)v;
+    if (seq == 0) return;                                                 // an intermediate launch of a long path: state only
+    const uint32_t first = (uint32_t)__shfl((int)v, (i / T::FACE) * T::FACE);
+    const bool solved = __all(lane >= T::S || v == first);               // every face equals its first sticker
+    const int p = lane < T::SLOTS ? lane : 0;
+    const uint32_t c0 = (uint32_t)__shfl((int)v, tb.slot[p][0]), c1 = (uint32_t)__shfl((int)v, tb.slot[p][1]), c2 = (uint32_t)__shfl((int)v, tb.slot[p][2]);
+    const uint32_t code = slot_code<T>(c0, c1, c2, tb.slot[p][3] != 0);
+    facade_write_onehot<T>(code, host_out, lane);
+    if (lane == 0) host_out[kFacadeDone] = solved ? 1 : 0;
     __threadfence_system();
     __syncthreads();
     if (lane == 0) __hip_atomic_store(reinterpret_cast<uint32_t *>(host_out + kFacadeSeq), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -627,26 +659,33 @@ constexpr int kFacadeChildCode = 32, kFacadeChildDone = 288, kFacadeDense = 512;
 template <class T>
 __global__ void __launch_bounds__(kWave) k_facade_expand(const uint8_t *st, uint32_t pitch, uint8_t *host_out, uint32_t seq, int dense) {
     __shared__ __attribute__((aligned(4))) uint8_t out_lds[320];
+    const FacadeTables<T> &tb = facade_tables<T>();
     const int lane = threadIdx.x;
-    Pk<1> s[T::S];
+    const int i = lane < T::S ? lane : 0;
+    const uint32_t v = st[(uint32_t)i * pitch];
+    for (int w = lane; w < 320 / 4; w += kWave) reinterpret_cast<uint32_t *>(out_lds)[w] = 0u;
+    __syncthreads();
+    {   // own code
+        const int p = lane < T::SLOTS ? lane : 0;
+        const uint32_t c0 = (uint32_t)__shfl((int)v, tb.slot[p][0]), c1 = (uint32_t)__shfl((int)v, tb.slot[p][1]), c2 = (uint32_t)__shfl((int)v, tb.slot[p][2]);
+        const uint32_t code = slot_code<T>(c0, c1, c2, tb.slot[p][3] != 0);
+        if (lane < T::SLOTS) out_lds[lane] = (uint8_t)code;
+    }
+    // child codes: one lane per (child, slot) pair, A * SLOTS pairs in rounds of 64
+    for (int q0 = 0; q0 < T::A * T::SLOTS; q0 += kWave) {
+        const int q = q0 + lane < T::A * T::SLOTS ? q0 + lane : 0;
+        const uint32_t c0 = (uint32_t)__shfl((int)v, tb.child[q][0]), c1 = (uint32_t)__shfl((int)v, tb.child[q][1]), c2 = (uint32_t)__shfl((int)v, tb.child[q][2]);
+        const uint32_t code = slot_code<T>(c0, c1, c2, tb.child[q][3] != 0);
+        if (q0 + lane < T::A * T::SLOTS) out_lds[kFacadeChildCode + q0 + lane] = (uint8_t)code;
+    }
+    // child solved flags: child a's sticker i is the parent's sticker perm[a][i]
+    const int f0 = (i / T::FACE) * T::FACE;
 #pragma unroll
-    for (int i = 0; i < T::S; ++i) s[i].d[0] = st[i * pitch];             // cube 0 only; uniform loads
-    FamilyCodes<T, 1> fam;
-    family_codes<T, 1>(s, fam);
-    if (lane == 0) {
-        Pk<1> pc[T::SLOTS];
-        family_pick<T, 1, -1>(fam, pc);
-#pragma unroll
-        for (int p = 0; p < T::SLOTS; ++p) out_lds[p] = (uint8_t)pc[p].d[0];
-        sfor<T::A>([&](auto ac) {
-            constexpr int a = decltype(ac)::value;
-            Pk<1> cc[T::SLOTS], c[T::S];
-            family_pick<T, 1, a>(fam, cc);
-#pragma unroll
-            for (int p = 0; p < T::SLOTS; ++p) out_lds[kFacadeChildCode + a * T::SLOTS + p] = (uint8_t)cc[p].d[0];
-            fixed_move<T, 1, a>(s, c);
-            out_lds[kFacadeChildDone + a] = (uint8_t)(done_bytes(unsolved<T, 1>(c)).d[0] & 1u);
-        });
+    for (int a = 0; a < T::A; ++a) {
+        const uint32_t cv = (uint32_t)__shfl((int)v, tb.perm[a][lane]);
+        const uint32_t first = (uint32_t)__shfl((int)cv, f0);
+        const bool solved = __all(lane >= T::S || cv == first);
+        if (lane == 0) out_lds[kFacadeChildDone + a] = solved ? 1 : 0;
     }
     __syncthreads();
     for (int w = lane; w < 320 / 4; w += kWave) reinterpret_cast<uint32_t *>(host_out)[w] = reinterpret_cast<const uint32_t *>(out_lds)[w];

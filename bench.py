@@ -177,6 +177,15 @@ def other_configs(torch, ops, _lib, dev, acts):
     t = timed(lambda: (ops.apply_moves(p4[0], p4[1], acts, n, CUBE, rew, done, code, _lib.FMT_CODE), p4.reverse()), 50)
     rec("3x3x3 batch 4M, apply_move + reward + done + fused compact one-hot code (20 B)", "k_step<Cube3,2,move,store,code>", n, "steps", 134, t)
     del code, a4, b4, p4
+    # 2x2x2 (24 stickers, 6 actions): 24 R + 24 W + 1 + 1 = 50 B per step
+    a2, b2 = ops.alloc_states(n, 2, dev), ops.alloc_states(n, 2, dev)
+    ops.fill_solved(a2, n, 2)
+    ops.scramble(a2, n, 2, 20, seed=1234)
+    acts2 = acts % 6
+    p2 = [a2, b2]
+    t = timed(lambda: (ops.apply_moves(p2[0], p2[1], acts2, n, 2, None, done), p2.reverse()), 100)
+    rec("2x2x2 batch 4M, apply_move + done (201 MB ping-pong: Infinity-Cache resident)", "k_step<Cube2,2,move,store>", n, "steps", 50, t)
+    del a2, b2, p2, acts2
     # fused dense one-hot in the layout model.py consumes
     for dt, fmt, name, bpc in ((torch.float32, _lib.FMT_F32, "f32", 1920), (torch.bfloat16, _lib.FMT_BF16, "bf16", 960)):
         oh = torch.empty((m, 20, 24), dtype=dt, device=dev)
@@ -299,6 +308,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dev_ms = float(t[0]), float(t[1])
 
+    copy_gbps = None
+    if rank == 0:
+        # the measured device-copy ceiling SURVEY 8d asks for beside the vendor peak: the runtime's own D2D copy of the same buffers
+        for _ in range(3):
+            bufs[1].copy_(bufs[0])
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(20):
+            bufs[1].copy_(bufs[0])
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 2 * bufs[0].numel() / (c0.elapsed_time(c1) / 20 * 1e-3) / 1e9
     configs = None
     if rank == 0 and world == 1 and not args.no_configs:
         del a, b, bufs
@@ -333,6 +354,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "k_step<Cube3,2,move,store,POL1>", "launch_us": launch_s * 1e6,
                          "algorithmic_bytes_per_launch": BYTES_PER_STEP * n,
+                         "device_copy_GBps": copy_gbps, "frac_of_device_copy": achieved / copy_gbps if copy_gbps else None,
+                         "device_copy_note": "hipMemcpy D2D (torch copy_) of the same 226 MB state buffer, read + write bytes",
                          "note": "input rows streamed (nt), output rows written through and kept (sc0 sc1): the next launch finds part of "
                                  "its input in the 256 MB Infinity Cache, so DRAM traffic is below the fabric traffic the counters show"},
         }

@@ -11,7 +11,10 @@ code -- lossless, 24x smaller than the printed one-hot.
   BatchedMCTS  R independent roots searched in lockstep: per simulation ONE replay launch brings all
                R leaves into a device buffer (paths padded with the no-op), ONE expansion launch
                produces R x A children (optionally on a side stream) and the value/policy net runs
-               once on the R leaves; tree statistics stay on the host.
+               once on the R leaves; tree statistics stay on the host, by default in librubiktree.so
+               (include/rubiktree.h: C++ / OpenMP, the reference's arithmetic and random draws bit for bit;
+               25 ms -> well under 1 ms of host time per simulation of 4096 roots), or in the pure-Python
+               tree below (`native=False`, kept as the cross-check).
 
 Tree rules restated from mcts.py: PUCT score U + W - L with U = c * P * sqrt(sum N) / (1 + N)
 (:148-169); W is the MAX of backed-up values (:124-125); a traversed edge gains the virtual loss and
@@ -137,11 +140,29 @@ class MCTS:
         return _puct_best(self.children_and_data[key], self.exploration_constant)
 
 
+class _RootView:
+    """trees[r][b"root"] of a native search: the root node's visit counts and values."""
+
+    def __init__(self, nat, r):
+        self._nat, self._r = nat, r
+
+    def __getitem__(self, key):
+        if key != b"root":
+            raise KeyError(key)
+        visits, value, _ = self._nat.root_stats(self._r)
+
+        class _N:
+            pass
+        node = _N()
+        node.visits, node.value = visits, value
+        return node
+
+
 class BatchedMCTS:
     """R roots searched in lockstep on one GPU (config 5: 4096 roots x 12 children per step)."""
 
     def __init__(self, model, root_stickers, n_roots, cube_size=3, cpuct=1.0, virtual_loss=150.0, value_min=-10.0,
-                 device="cuda", overlap=False, rngs=None, graph=False):
+                 device="cuda", overlap=False, rngs=None, graph=False, native=True):
         """rngs: optional list of `random.Random` (one per root) for the untried-node draws (mcts.py:69-70); with
         root r's generator seeded like a stand-alone run, root r's search is that run (default: the global `random`).
         overlap: run the expansion on a side stream next to the net forward.  Off by default: at 4096 leaves the
@@ -153,15 +174,32 @@ class BatchedMCTS:
         (self.R, self.C), self.A = get_env_config(cube_size)
         self.roots = root_stickers                      # tiled state buffer [tiles, S, pitch]
         self.work = torch.empty_like(root_stickers)
-        self.trees = [dict() for _ in range(self.n)]
-        self.solution = [None] * self.n
-        self.sims_used = [0] * self.n
         self.rngs = rngs
+        self.native = None
+        if native:
+            from ._tree import NativeTrees
+            self.native = NativeTrees(self.n, self.A, ops.N_SLOTS[cube_size], cpuct, virtual_loss, value_min, rngs)
+        else:
+            self.trees = [dict() for _ in range(self.n)]
+            self.solution = [None] * self.n
+            self.sims_used = [0] * self.n
         self.onehot = torch.empty((self.n, self.R, self.C), dtype=torch.float32, device=self.dev)
         self.code = ops.alloc_code(self.n, cube_size, self.dev, root_stickers.shape[-1])
         self.ex = ops.expand_buffers(self.n, cube_size, self.dev, root_stickers.shape[-1], children=False, codes=True)
         self.side = torch.cuda.Stream(self.dev) if overlap else None
         self.graph, self._graphs, self._paths, self._host = bool(graph), {}, None, None
+
+    def __getattr__(self, name):
+        # result views of the native trees under the names the Python tree uses (solution, sims_used, trees[r][b"root"])
+        nat = self.__dict__.get("native")
+        if nat is not None:
+            if name == "solution":
+                return [nat.solution(r) for r in range(self.n)]
+            if name == "sims_used":
+                return nat.sims_used().tolist()
+            if name == "trees":
+                return [_RootView(nat, r) for r in range(self.n)]
+        raise AttributeError(name)
 
     def _device_step(self, depth):
         """Kernels of one simulation, all on the current stream (capturable): roots -> work, replay `depth`
@@ -232,6 +270,14 @@ class BatchedMCTS:
 
     def simulate(self):
         """One simulation for every unsolved root.  Returns the number of roots solved so far."""
+        if self.native is not None:
+            paths = self.native.select()                                          # R tree descents (C++)
+            leaf_code, child_code, solved, value, policy = self.leaves_step(paths)   # device: replay, expand, encode, net
+            done = self.native.update(leaf_code, child_code, solved, value, policy)  # R insertions + back-propagations (C++)
+            self._sims = getattr(self, "_sims", 0) + 1
+            if self._sims % 16 == 0 and _lib.read_status(self.dev) & _lib.STATUS_BAD_ACTION:
+                raise IndexError("action out of range")                 # cube_env.py:86,96
+            return done
         n = self.n
         paths, trails = [], []
         for r in range(n):

@@ -76,8 +76,16 @@ def test_abi_exports_every_declared_symbol():
     assert len(declared) >= 15
     for name in declared:
         assert hasattr(L, name), name
-    assert L.rc_version() >= 100
+    assert L.rc_version() >= 200 and len(declared) >= 23
     assert L.rc_last_error() == b"" or isinstance(L.rc_last_error(), bytes)
+    # include/rubiktree.h <-> librubiktree.so (host-side trees of the lockstep search)
+    from rubiks_cube_solver_amd import _tree
+    T = _tree.tree_lib()
+    header = open(os.path.join(ROOT, "include", "rubiktree.h")).read()
+    declared = set(re.findall(r"^(?:int|void|rc_tree \*)\s*(rc_tree_\w+)\(", header, re.M))
+    assert len(declared) == 10, declared
+    for name in declared:
+        assert hasattr(T, name), name
 
 
 def test_abi_tables_equal_package_tables():

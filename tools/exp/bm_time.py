@@ -7,14 +7,14 @@ from bench_cfg5 import DeepCubeStandIn
 n, cs = 4096, 3
 model = DeepCubeStandIn().cuda().eval()
 leaves = ops.alloc_states(n, cs, "cuda"); ops.fill_solved(leaves, n, cs); ops.scramble(leaves, n, cs, 20, seed=7)
-for graph in (False, True):
-    bm = BatchedMCTS(model, leaves, n, cs, graph=graph)
+for graph, native in ((True, True), (False, True), (True, False)):
+    bm = BatchedMCTS(model, leaves, n, cs, graph=graph, native=native)
     ts = []
     for s in range(30):
         t0 = time.perf_counter(); bm.simulate(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-    print("graph", graph, "ms per simulation (first 5 / mean of last 20):", [round(t * 1e3, 1) for t in ts[:5]], round(np.mean(ts[10:]) * 1e3, 2))
+    print("native", native, "graph", graph, "ms per simulation (first 5 / mean of last 20):", [round(t * 1e3, 1) for t in ts[:5]], round(np.mean(ts[10:]) * 1e3, 2))
 import cProfile, pstats
-bm = BatchedMCTS(model, leaves, n, cs, graph=True)
+bm = BatchedMCTS(model, leaves, n, cs, graph=True, native=True)
 for _ in range(10): bm.simulate()
 pr = cProfile.Profile(); pr.enable()
 for _ in range(10): bm.simulate()

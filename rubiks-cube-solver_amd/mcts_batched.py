@@ -186,6 +186,12 @@ class BatchedMCTS:
         self.onehot = torch.empty((self.n, self.R, self.C), dtype=torch.float32, device=self.dev)
         self.code = ops.alloc_code(self.n, cube_size, self.dev, root_stickers.shape[-1])
         self.ex = ops.expand_buffers(self.n, cube_size, self.dev, root_stickers.shape[-1], children=False, codes=True)
+        SL = ops.N_SLOTS[cube_size]
+        # results in the host's layout ([root][...]) are produced ON the device (three small transposing copies, inside the
+        # captured graph), so the download needs no reshuffle on the host
+        self._leaf_aos = torch.empty((self.n, SL), dtype=torch.uint8, device=self.dev)
+        self._child_aos = torch.empty((self.n, self.A, SL), dtype=torch.uint8, device=self.dev)
+        self._solved_aos = torch.empty((self.n, self.A), dtype=torch.uint8, device=self.dev)
         self.side = torch.cuda.Stream(self.dev) if overlap else None
         self.graph, self._graphs, self._paths, self._host = bool(graph), {}, None, None
 
@@ -221,6 +227,10 @@ class BatchedMCTS:
         policy = torch.softmax(logits, dim=-1)          # model.py:89
         if self.side is not None:
             torch.cuda.current_stream(self.dev).wait_stream(self.side)
+        self._leaf_aos.copy_(ops.to_aos(self.code, n))
+        cc = self.ex["child_code"]                                              # [A, tiles, SLOTS, pitch]
+        self._child_aos.copy_(cc.permute(1, 3, 0, 2).reshape(-1, self.A, cc.shape[2])[:n])
+        self._solved_aos.copy_(self.ex["child_solved"][:, :n].t())
         return value, policy
 
     @torch.no_grad()
@@ -254,19 +264,16 @@ class BatchedMCTS:
             g.replay()
         else:
             value, policy = self._device_step(depth)
-        # one batch of raw downloads into pinned memory, one sync; the [tile][slot][column] -> [root][slot]
-        # reshuffle of ~1 MB happens on the host
+        # one batch of downloads into pinned memory, one sync
         if self._host is None:
             pin = lambda t: torch.empty(t.shape, dtype=t.dtype).pin_memory()
-            self._host = [pin(self.code), pin(self.ex["child_code"]), pin(self.ex["child_solved"]), pin(value), pin(policy)]
-        for h, d in zip(self._host, (self.code, self.ex["child_code"], self.ex["child_solved"], value, policy)):
+            self._host = [pin(self._leaf_aos), pin(self._child_aos), pin(self._solved_aos), pin(value), pin(policy)]
+        for h, d in zip(self._host, (self._leaf_aos, self._child_aos, self._solved_aos, value, policy)):
             h.copy_(d, non_blocking=True)
         torch.cuda.current_stream(self.dev).synchronize()
         code_h, cc_h, cs_h, v_h, p_h = (h.numpy() for h in self._host)
-        leaf_code = code_h.transpose(0, 2, 1).reshape(-1, code_h.shape[1])[:n]                      # [n, SLOTS]
-        child_code = cc_h.transpose(1, 3, 0, 2).reshape(-1, self.A, cc_h.shape[2])[:n]             # [n, A, SLOTS]
-        solved = cs_h[:, :n].T.astype(bool)
-        return leaf_code, child_code, solved, v_h.reshape(-1).copy(), p_h.copy()
+        # copies: the pinned buffers are overwritten by the next simulation (the Python tree keeps policy rows)
+        return code_h.copy(), cc_h.copy(), cs_h.astype(bool), v_h.reshape(-1).copy(), p_h.copy()
 
     def simulate(self):
         """One simulation for every unsolved root.  Returns the number of roots solved so far."""

@@ -147,6 +147,18 @@ def _run(short):
         for _ in range(20):
             bm.leaves_step(paths)
         res[f"batched_mcts_leaves_step_with_d2h_{name}_us"] = (time.perf_counter() - t0) / 20 * 1e6
+    # whole simulations of the lockstep search (host trees in librubiktree.so + the device step + downloads)
+    import random
+    bm = BatchedMCTS(model, leaves, n, cs, graph=True, rngs=[random.Random(r) for r in range(n)])
+    for _ in range(10):
+        bm.simulate()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        bm.simulate()
+    torch.cuda.synchronize()
+    res["batched_mcts_simulate_native_tree_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+    res["batched_mcts_note"] = "simulations 11-30 of 4096 roots, per-root generators, hipGraph device step; the pure-Python tree needs 100-500 ms per simulation"
     return res
 
 

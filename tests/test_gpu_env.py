@@ -416,8 +416,9 @@ def test_greedy_rollout_matches_reference_golden(mod, golden, graph):
         assert int((steps > 0).sum()) == 14
 
 
+@pytest.mark.parametrize("native", [True, False])
 @pytest.mark.parametrize("graph", [False, True])
-def test_batched_mcts_reproduces_reference_runs_in_lockstep(mod, golden, graph):
+def test_batched_mcts_reproduces_reference_runs_in_lockstep(mod, golden, graph, native):
     """All 24 scrambles of fixture G8 searched TOGETHER by BatchedMCTS (one replay + one expansion launch + one net
     forward per simulation), each root with its own seeded generator: every root ends like the reference's
     stand-alone MCTS run (simulations used, action list, root visit counts, root values)."""
@@ -434,7 +435,7 @@ def test_batched_mcts_reproduces_reference_runs_in_lockstep(mod, golden, graph):
     n = len(g["seeds"])
     venv = mod.VecCubeEnv(n, "cuda", 3, obs=None)
     venv.reset(seeds=[int(s) for s in g["seeds"]], scramble_count=[int(k) for k in g["ks"]])
-    bm = BatchedMCTS(model, venv.stickers, n, 3, rngs=[random.Random(int(s)) for s in g["random_seed"]], graph=graph)
+    bm = BatchedMCTS(model, venv.stickers, n, 3, rngs=[random.Random(int(s)) for s in g["random_seed"]], graph=graph, native=native)   # librubiktree.so | the Python tree
     for _ in range(60):
         bm.simulate()
     for r in range(n):

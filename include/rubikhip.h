@@ -219,7 +219,7 @@ const char *rc_last_error(void);
 
 /* Tuning override of the *_ex entry points (benchmarks and tests that must reach every kernel
  * instantiation; there is NO process-global knob).  0 = the measured defaults.  Decimal digits:
- *   units      pack width: 1,2,3 -> 4,8,16 cubes per lane (expansion / ADI: 1,2 only)
+ *   units      pack width: 1,2 -> 4,8 cubes per lane
  *   tens       row-traffic policy of the step kernel: 1 stream in / stream out, 2 default-cached,
  *              3 stream in / keep the output in the Infinity Cache
  *   thousands  (2 digits) parts per walk group for expansion / ADI (1..A, rounded up to a divisor of A)

@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(256) k_adi_targets(const float *child_value, c
 // it polls the sequence word.  One wave; every lane carries the same (single-cube) pack, lane l then
 // writes bytes 8l..8l+7 of the one-hot.  Layout of `host_out` (512 bytes): [0, R*C) one-hot, [496] done,
 // [504..507] sequence (written last, after a system-scope fence).
-constexpr int kFacadeBytes = 512, kFacadeDone = 496, kFacadeSeq = 504;
+constexpr int kFacadeDone = 496, kFacadeSeq = 504;
 
 constexpr int kFacadeMaxActs = 60;
 struct FacadeActs {
@@ -756,15 +756,16 @@ int by_size(int cube_size, F &&f) {
 }
 
 // Per-call tuning override of the *_ex entry points (0 = the measured defaults).  Decimal digits:
-//   units      pack width: 1,2,3 -> V = 1,2,4 (4, 8, 16 cubes per lane)
+//   units      pack width: 1,2 -> V = 1,2 (4, 8 cubes per lane)
 //   tens       row-traffic policy of the step kernel: 1 -> POL 2 (stream), 2 -> POL 0 (cached), 3 -> POL 1 (keep)
 //   thousands  (2 digits) parts per walk group for expansion / ADI (1..A)
 //   100000s    dense one-hot tile: 1 -> 64, 2 -> 256 cubes per workgroup
-// Measured on MI355X at 4M cubes (tools/exp/exp_step.hip, exp_step2.hip): V = 2 (8 cubes per lane, dwordx2
-// rows) beats V = 1 and V = 4 for the step kernel; the policy follows the working set (RowPolicy).
+// Measured on MI355X at 4M cubes (tools/exp/exp_step.hip, exp_step2.hip): V = 2 (8 cubes per lane, dwordx2 rows)
+// beats V = 1; V = 4 (16 cubes per lane, 345 VGPRs) never beat V = 2 and is no longer instantiated.  The row-traffic
+// policy follows the working set (RowPolicy).
 int pick_v(int64_t n, int variant) {
     const int v = variant % 10;
-    if (v >= 1 && v <= 3) return v == 1 ? 1 : v == 2 ? 2 : 4;
+    if (v == 1 || v == 2) return v;
     return n >= (int64_t)1 << 18 ? 2 : 1;
 }
 constexpr int64_t kMallBytes = (int64_t)240 << 20;   // what we count on of the 256 MiB Infinity Cache
@@ -797,11 +798,7 @@ int launch_step(const StepArgs &a, hipStream_t st, int variant) {
 
 template <class T, bool MOVE, bool STORE, bool CODE>
 int dispatch_step(const StepArgs &a, hipStream_t st, int variant) {
-    switch (pick_v(a.n, variant)) {
-        case 4: return launch_step<T, 4, MOVE, STORE, CODE>(a, st, variant);
-        case 2: return launch_step<T, 2, MOVE, STORE, CODE>(a, st, variant);
-        default: return launch_step<T, 1, MOVE, STORE, CODE>(a, st, variant);
-    }
+    return pick_v(a.n, variant) == 2 ? launch_step<T, 2, MOVE, STORE, CODE>(a, st, variant) : launch_step<T, 1, MOVE, STORE, CODE>(a, st, variant);
 }
 
 // Measured at 1M cubes (tools/microbench.py densetile): 256-cube tiles 5.4 TB/s (f32) / 6.3 TB/s (u8) against

@@ -193,7 +193,7 @@ def test_step_policies_agree_at_scale(ops, L, cs):
     ref_done = torch.empty(n, dtype=torch.uint8, device="cuda")
     ops.apply_moves(st, ref, acts, n, cs, None, ref_done, variant=21)              # narrow pack, default-cached
     valid = ops.to_aos(ref, n)
-    for variant in (0, 11, 12, 22, 31, 32, 13, 23, 33):
+    for variant in (0, 1, 2, 11, 12, 22, 31, 32):
         out = torch.zeros_like(st)
         done = torch.zeros_like(ref_done)
         ops.apply_moves(st, out, acts, n, cs, None, done, variant=variant)

@@ -67,6 +67,37 @@ __global__ void __launch_bounds__(64) k_dense_wave(const unsigned char *code, in
     }
 }
 
+
+// 1024-thread workgroups, one per CU, sweeping memory like the runtime's fill kernel: 960 threads write 8 whole cubes
+// (15360 contiguous bytes) per pass, TILE cubes per iteration, grid-stride over tiles.
+template <int TILE, int AUX>
+__global__ void __launch_bounds__(1024) k_dense_big(const unsigned char *code, int64_t n, int64_t pitch, float *dense) {
+    constexpr int TP = TILE + 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[20 * TP];
+    const int tid = threadIdx.x;
+    for (int64_t tile0 = (int64_t)blockIdx.x * TILE; tile0 < n; tile0 += (int64_t)gridDim.x * TILE) {
+        if (tid * 4 < TILE) {
+#pragma unroll
+            for (int p = 0; p < 20; ++p) *reinterpret_cast<unsigned *>(lds + p * TP + tid * 4) = *reinterpret_cast<const unsigned *>(code + p * pitch + tile0 + tid * 4);
+        }
+        __syncthreads();
+        if (tid < 960) {
+            const int sub = tid / 120, k = tid - sub * 120;
+            const int r = k / 6;
+            const unsigned c0 = (unsigned)(k - r * 6) * 4u;
+            const __amdgpu_buffer_rsrc_t srd = make_srd(dense + tile0 * 480);
+            unsigned off = (unsigned)sub * 1920u + (unsigned)k * 16u;
+            const int ncubes = n - tile0 < TILE ? (int)(n - tile0) : TILE;
+            for (int cube = sub; cube < ncubes; cube += 8, off += 8u * 1920u) {
+                const unsigned d = (unsigned)lds[r * TP + cube] - c0;
+                u32x4 u = {d == 0 ? 0x3F800000u : 0u, d == 1 ? 0x3F800000u : 0u, d == 2 ? 0x3F800000u : 0u, d == 3 ? 0x3F800000u : 0u};
+                __builtin_amdgcn_raw_buffer_store_b128(u, srd, off, 0, AUX);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <class F> double timeit(F &&f, int iters = 10) {
     for (int i = 0; i < 3; i++) f();
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -103,6 +134,9 @@ int main() {
 #define RUNW(TILE, AUX, GRID) { const int64_t tiles = (n + TILE - 1) / TILE; const int64_t g = std::min<int64_t>(tiles, GRID); \
         double t = timeit([&] { hipLaunchKernelGGL((k_dense_wave<TILE, AUX>), dim3(g), dim3(64), 0, 0, code, n, pitch, out); }); \
         printf("wave tile %4d           aux %2d grid %6lld: %7.1f us %7.1f GB/s\n", TILE, AUX, (long long)g, t * 1e6, bytes / t / 1e9); fflush(stdout); }
+#define RUNBIG(TILE, AUX, GRID) { double t = timeit([&] { hipLaunchKernelGGL((k_dense_big<TILE, AUX>), dim3(GRID), dim3(1024), 0, 0, code, n, pitch, out); }); \
+        printf("big  tile %4d           aux %2d grid %6d: %7.1f us %7.1f GB/s\n", TILE, AUX, GRID, t * 1e6, bytes / t / 1e9); fflush(stdout); }
+        RUNBIG(32, 19, 256); RUNBIG(64, 19, 256); RUNBIG(128, 19, 256); RUNBIG(64, 19, 512); RUNBIG(64, 2, 256); RUNBIG(64, 0, 256); RUNBIG(256, 19, 256); RUNBIG(8, 19, 256); RUNBIG(16, 19, 256);
         RUN(8, true, 19, 256); RUN(16, true, 19, 256); RUN(32, true, 19, 256); RUN(64, true, 19, 256); RUN(16, true, 0, 256); RUN(16, true, 2, 256); RUN(16, true, 17, 256);
         RUN(16, true, 19, 1024); RUN(32, true, 19, 1024); RUN(64, true, 19, 512);
         RUN(256, false, 19, 0); RUN(256, true, 19, 2048);

@@ -25,11 +25,9 @@ acts = torch.randint(0, 12, (n,), dtype=torch.uint8, device=dev); done = torch.e
 res = {k: [] for k in list(variants) + ["step4M"]}
 for r in range(6):
     for name, (pt, ab, parts) in variants.items():
-        L.rc_set_variant(parts)
-        fn = lambda: ops.adi_generate(W, D, 3, pt, dev, seed=2024, **ab)
+        fn = lambda: ops.adi_generate(W, D, 3, pt, dev, seed=2024, variant=parts, **ab)   # per-call override (round 2)
         if r == 0: run(fn, 3)
         res[name].append(run(fn, 20))
-    L.rc_set_variant(0)
     fn = lambda: ops.apply_moves(a, b, acts, n, 3, None, done)
     res["step4M"].append(run(fn, 50))
 for k, v in res.items():

@@ -49,9 +49,10 @@ __global__ void __launch_bounds__(kWave) k_fill_solved(uint8_t *base, int64_t n,
     const int64_t g0 = (int64_t)blockIdx.x * (kWave * 16);
     const uint32_t lo = threadIdx.x * 16;
     if (g0 + lo >= n) return;
-    uint8_t *row = base + tile_off(g0, pitch, shift, T::S);
+    const __amdgpu_buffer_rsrc_t r = make_srd(base + tile_off(g0, pitch, shift, T::S));
+    const uint32_t rs = (uint32_t)pitch;
 #pragma unroll
-    for (int s = 0; s < T::S; ++s) { st<4, false>(row + lo, splat<4>((uint32_t)(s / T::FACE) * 0x01010101u)); row += pitch; }
+    for (int s = 0; s < T::S; ++s) bst<4, kAuxCached>(r, lo, s * rs, splat<4>((uint32_t)(s / T::FACE) * 0x01010101u));
 }
 
 // ------------------------------------------------------------------------------ step
@@ -168,9 +169,10 @@ __global__ void __launch_bounds__(kDenseBlock) k_step_dense(StepArgs a, E *dense
     if (lo < TILE && n0 < a.n) {
         Pk<1> s[T::S];
         {
-            const uint8_t *row = a.in + tile_off(tile0, a.pitch_in, a.sh_in, T::S);
+            const __amdgpu_buffer_rsrc_t r = make_srd(a.in + tile_off(tile0, a.pitch_in, a.sh_in, T::S));
+            const uint32_t rs = (uint32_t)a.pitch_in;
 #pragma unroll
-            for (int i = 0; i < T::S; ++i) { s[i] = ld<1, false>(row + lo); row += a.pitch_in; }
+            for (int i = 0; i < T::S; ++i) s[i] = bld<1, kAuxCached>(r, lo, i * rs);
         }
         if constexpr (MOVE) {
             const Pk<1> act = ld_tail<1>(a.actions, n0, a.n, 0);
@@ -183,9 +185,10 @@ __global__ void __launch_bounds__(kDenseBlock) k_step_dense(StepArgs a, E *dense
             for (int i = 0; i < T::S; ++i) s[i] = o[i];
         }
         if constexpr (STORE) {
-            uint8_t *row = a.out + tile_off(tile0, a.pitch_out, a.sh_out, T::S);
+            const __amdgpu_buffer_rsrc_t r = make_srd(a.out + tile_off(tile0, a.pitch_out, a.sh_out, T::S));
+            const uint32_t rs = (uint32_t)a.pitch_out;
 #pragma unroll
-            for (int i = 0; i < T::S; ++i) { st<1, false>(row + lo, s[i]); row += a.pitch_out; }
+            for (int i = 0; i < T::S; ++i) bst<1, kAuxCached>(r, lo, i * rs, s[i]);
         }
         if (a.done != nullptr || a.reward != nullptr) {
             const Pk<1> dn = done_bytes(unsolved<T, 1>(s));
@@ -212,9 +215,10 @@ __global__ void __launch_bounds__(kDenseBlock) k_code_to_dense(const uint8_t *co
     const uint32_t lo = threadIdx.x * 4;
     for (int64_t tile0 = (int64_t)blockIdx.x * TILE; tile0 < n; tile0 += (int64_t)gridDim.x * TILE) {
     if (lo < TILE && tile0 + lo < n) {
-        const uint8_t *row = code + tile_off(tile0, code_pitch, shift, T::SLOTS) + lo;
+        const __amdgpu_buffer_rsrc_t r = make_srd(code + tile_off(tile0, code_pitch, shift, T::SLOTS));
+        const uint32_t rs = (uint32_t)code_pitch;
 #pragma unroll
-        for (int p = 0; p < T::SLOTS; ++p) { *reinterpret_cast<uint32_t *>(lds_code + p * TP + lo) = ld<1, false>(row).d[0]; row += code_pitch; }
+        for (int p = 0; p < T::SLOTS; ++p) *reinterpret_cast<uint32_t *>(lds_code + p * TP + lo) = bld<1, kAuxCached>(r, lo, p * rs).d[0];
     }
     __syncthreads();
     const int64_t left = n - tile0;
@@ -430,11 +434,10 @@ __global__ void __launch_bounds__(kWave) k_scramble(ScrambleArgs a) {
     const int64_t n0 = g0 + lo;
     if (n0 >= a.n) return;
     Pk<V> s[T::S];
-    {
-        const uint8_t *row = a.st + tile_off(g0, a.pitch, a.shift, T::S);
+    const __amdgpu_buffer_rsrc_t rows = make_srd(a.st + tile_off(g0, a.pitch, a.shift, T::S));
+    const uint32_t rs = (uint32_t)a.pitch;
 #pragma unroll
-        for (int i = 0; i < T::S; ++i) { s[i] = ld<V, false>(row + lo); row += a.pitch; }
-    }
+    for (int i = 0; i < T::S; ++i) s[i] = bld<V, kAuxCached>(rows, lo, i * rs);
     WalkRng rng[4 * V];
     if (a.actions_in == nullptr) {
 #pragma unroll
@@ -459,11 +462,8 @@ __global__ void __launch_bounds__(kWave) k_scramble(ScrambleArgs a) {
 #pragma unroll
         for (int i = 0; i < T::S; ++i) s[i] = o[i];
     }
-    {
-        uint8_t *row = a.st + tile_off(g0, a.pitch, a.shift, T::S);
 #pragma unroll
-        for (int i = 0; i < T::S; ++i) { st<V, false>(row + lo, s[i]); row += a.pitch; }
-    }
+    for (int i = 0; i < T::S; ++i) bst<V, kAuxCached>(rows, lo, i * rs, s[i]);
     if (a.done != nullptr || a.reward != nullptr) {
         const Pk<V> dn = done_bytes(unsolved<T, V>(s));
         if (a.done) st_tail<V>(a.done, n0, a.n, dn);

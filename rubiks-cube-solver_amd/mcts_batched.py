@@ -196,15 +196,23 @@ class BatchedMCTS:
         self.graph, self._graphs, self._paths, self._host = bool(graph), {}, None, None
 
     def __getattr__(self, name):
-        # result views of the native trees under the names the Python tree uses (solution, sims_used, trees[r][b"root"])
+        # result views of the native trees under the names the Python tree uses (solution, sims_used, trees[r][b"root"]);
+        # fetched once per simulation, not once per access
         nat = self.__dict__.get("native")
-        if nat is not None:
-            if name == "solution":
-                return [nat.solution(r) for r in range(self.n)]
-            if name == "sims_used":
-                return nat.sims_used().tolist()
-            if name == "trees":
-                return [_RootView(nat, r) for r in range(self.n)]
+        if nat is not None and name in ("solution", "sims_used", "trees"):
+            cache = self.__dict__.setdefault("_views", {})
+            stamp = self.__dict__.get("_sims", 0)
+            if cache.get("stamp") != stamp:
+                cache.clear()
+                cache["stamp"] = stamp
+            if name not in cache:
+                if name == "solution":
+                    cache[name] = [nat.solution(r) for r in range(self.n)]
+                elif name == "sims_used":
+                    cache[name] = nat.sims_used().tolist()
+                else:
+                    cache[name] = [_RootView(nat, r) for r in range(self.n)]
+            return cache[name]
         raise AttributeError(name)
 
     def _device_step(self, depth):

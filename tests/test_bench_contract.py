@@ -40,6 +40,21 @@ def test_bench_json_line():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["value"] > 1e9                     # the round's floor target: >= 1e9 cube-move steps/s
+    assert r["traffic_source"] and r["device_copy_GBps"] > 1000
+    # the other BASELINE configs ride in the same line, each with its own roofline sub-record
+    recs = d["configs"]["records"]
+    names = " | ".join(x["config"] for x in recs)
+    for needle in ("config 2", "config 3", "fused compact one-hot code", "fused dense f32", "fused dense bf16", "expansion of 1M", "2x2x2"):
+        assert needle in names, needle
+    for x in recs:
+        assert x["kernel"].startswith("k_") and x["launch_us"] > 0 and x["value"] > 0
+        rr = x["roofline"]
+        assert rr["peak"] == 8000.0 and 0.05 < rr["frac"] < 1.0 and abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-9
+        assert rr["algorithmic_bytes_per_launch"] > 0
+    adi = [x for x in recs if x["config"].startswith("config 3")][0]
+    assert adi["roofline"]["bytes_per_unit"] == 715 and adi["roofline"]["frac"] > 0.6
+    assert "hipgraph_serial_step_us" in d["configs"]["config5_mcts_4096_leaves"]
+    assert d["configs"]["facade_batch1"]["CubeEnv.step_us"] < 24.6          # faster than the reference's own batch-1 step
 
 
 @pytest.mark.gpu

@@ -303,8 +303,14 @@ def main():
     elapsed = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1)                                     # HIP events on the launch stream
     assert _lib.read_status(dev) == 0
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)                                     # reporting only: per-GPU figures beside the aggregate (config 4)
+        per_rank = [{"rank": r, "ms_per_step": float(x[0]) / args.steps * 1e3, "launch_us": float(x[1]) / args.steps * 1e3,
+                     "steps_per_s": n * args.steps / float(x[0]), "GBps": BYTES_PER_STEP * n / (float(x[1]) * 1e-3 / args.steps) / 1e9}
+                    for r, x in enumerate(every)]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dev_ms = float(t[0]), float(t[1])
 
@@ -359,6 +365,10 @@ def main():
                          "note": "input rows streamed (nt), output rows written through and kept (sc0 sc1): the next launch finds part of "
                                  "its input in the 256 MB Infinity Cache, so DRAM traffic is below the fabric traffic the counters show"},
         }
+        if per_rank:
+            out["per_gpu"] = per_rank
+            out["roofline"]["aggregate_GBps"] = sum(r["GBps"] for r in per_rank)
+            out["roofline"]["aggregate_frac_of_n_x_peak"] = out["roofline"]["aggregate_GBps"] / (HBM_PEAK_GBPS * world)
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         if configs:

@@ -70,3 +70,5 @@ def test_bench_two_ranks_rehearsal():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d and d["value"] > 1e9
+    assert [r["rank"] for r in d["per_gpu"]] == [0, 1] and all(r["steps_per_s"] > 1e9 for r in d["per_gpu"])
+    assert d["roofline"]["aggregate_GBps"] > 0 and "configs" not in d

@@ -639,3 +639,24 @@ def test_checkpoint_traces_replay_on_the_hip_222_path(mod, golden):
     assert (solve_step == g["solve_step"]).all()
     assert (solve_step > 0).all()                                       # the authors' policy solves every one of them
     env.check_actions()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_batched_mcts_side_stream_expansion_is_equivalent(mod, graph):
+    """BatchedMCTS(overlap=True) runs the expansion on a side stream next to the net forward (config 5's "interleaved"
+    shape).  Same roots, same per-root generators: identical searches with and without it, eager and as a hipGraph."""
+    import random
+
+    from rubiks_cube_solver_amd.mcts_batched import BatchedMCTS
+    n = 200
+    net = TinyNet([20, 24], 12, seed=5).cuda()
+    venv = mod.VecCubeEnv(n, "cuda", 3, obs=None)
+    venv.reset(seeds=list(range(n)), scramble_count=[2 + (i % 5) for i in range(n)])
+    runs = []
+    for overlap in (False, True):
+        bm = BatchedMCTS(net, venv.stickers, n, 3, rngs=[random.Random(50 + r) for r in range(n)], graph=graph, overlap=overlap)
+        for _ in range(25):
+            bm.simulate()
+        runs.append((bm.solution, bm.sims_used, [bm.trees[r][b"root"].visits for r in range(n)]))
+    assert runs[0] == runs[1]
+    assert sum(s is not None for s in runs[0][0]) >= 10               # a random net still finishes the shallow scrambles

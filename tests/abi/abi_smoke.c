@@ -57,6 +57,9 @@ int main(void) {
     const uint8_t undo[4] = {0, 4, 1, 5};                      /* U R U' R' = (R U R' U')^-1: one launch */
     RC(rc_facade_steps(st, pitch, 3, undo, 4, pinned, 9u, 1, NULL));
     if (pinned[496] != 1) return 12;
+    RC(rc_facade_step(st, pitch, 3, 12, pinned, 77u, 0, NULL));            /* wait = 0: the caller polls (here: a stream sync); 12 = no-op */
+    CK(hipDeviceSynchronize());
+    if (*(volatile uint32_t *)(pinned + 504) != 77u || pinned[496] != 1) return 15;
     RC(rc_facade_expand(st, pitch, 3, pinned, 10u, 1, 1, NULL));
     for (int a = 0; a < 12; ++a) if (pinned[288 + a] != 0) return 13;      /* no child of the solved cube is solved */
     /* per-call tuning override instead of any global knob */

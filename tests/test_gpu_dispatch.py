@@ -96,6 +96,14 @@ def test_adi_every_parts_value(ops, L, oracle, cs, v, n_walks, depth, pitch):
         assert torch.equal(b2["children"], bufs["children"]) or \
             (untile(ops, b2["children"], n_walks, 2).transpose(2, 0, 1, 3) == exp["children"]).all()
         assert (b2["child_solved"][..., :n_walks].cpu().numpy().transpose(2, 0, 1) == exp["child_solved"]).all(), parts
+        if parts in (1, 2):   # replaying the recorded moves (actions_in) through the same instantiation gives the same bytes
+            wp = b2["actions_out"].shape[1]
+            a_in = torch.zeros((depth, wp), dtype=torch.uint8, device="cuda")
+            a_in[:, :n_walks] = torch.from_numpy(np.ascontiguousarray(exp["actions"].T)).cuda()
+            pt, b3 = ops.adi_buffers(n_walks, depth, cs, "cuda", pitch or L.pitch_for(n_walks), parents=True, children=True)
+            ops.adi_generate(n_walks, depth, cs, pt, "cuda", actions_in=a_in, variant=parts * 1000 + v, **b3)
+            assert (untile(ops, b3["children"], n_walks, 2).transpose(2, 0, 1, 3) == exp["children"]).all(), parts
+            assert (b3["actions_out"][:, :n_walks].cpu().numpy().T == exp["actions"]).all(), parts
     assert L.read_status() == 0
 
 

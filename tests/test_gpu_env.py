@@ -660,3 +660,26 @@ def test_batched_mcts_side_stream_expansion_is_equivalent(mod, graph):
         runs.append((bm.solution, bm.sims_used, [bm.trees[r][b"root"].visits for r in range(n)]))
     assert runs[0] == runs[1]
     assert sum(s is not None for s in runs[0][0]) >= 10               # a random net still finishes the shallow scrambles
+
+
+def test_vec_env_debug_action_check_and_clone(mod):
+    """debug_check_every=K surfaces an out-of-range device action as the reference's IndexError (cube_env.py:86,96) within K
+    steps; clone() is an independent deep copy (lean=True copies the state only)."""
+    env = mod.VecCubeEnv(64, "cuda", 3, obs="code", debug_check_every=2)
+    env.reset(scramble_count=3)
+    good = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    bad = good.clone()
+    bad[7] = 200
+    env.step(good)
+    twin, lean = env.clone(), env.clone(lean=True)
+    assert torch.equal(twin.stickers, env.stickers) and torch.equal(twin.done, env.done) and torch.equal(lean.stickers, env.stickers)
+    env.step(bad)                                 # step 2: the check runs before the launch, nothing bad seen yet
+    with pytest.raises(IndexError):
+        env.step(good)                            # step 3 launches; step 4's check ...
+        env.step(good)                            # ... raises here at the latest
+    assert not torch.equal(twin.stickers, env.stickers)        # the copies did not follow
+    twin.step(good)
+    lean.step(good)
+    assert torch.equal(twin.sim_cube, lean.sim_cube)
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(63, dtype=torch.uint8, device="cuda"))   # wrong length is refused on the fast path too

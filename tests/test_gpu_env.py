@@ -323,6 +323,12 @@ def test_mcts_class_and_batched_mcts(mod, oracle):
         found = tree.train(state, env)
         if found is not None:
             break
+    root_key = tree.key_of_state(state)
+    if root_key in tree.children_and_data and sum(tree.children_and_data[root_key].visits):
+        node = tree.children_and_data[root_key]                   # mcts.py:132-154 under its reference name
+        tot = np.sqrt(sum(node.visits))
+        score = [np.float32(1.0) * node.policy[i] * np.float32(tot / (1 + node.visits[i])) + np.float32(node.value[i]) - np.float32(node.vloss[i]) for i in range(12)]
+        assert tree.get_most_promising_action_index(root_key) == int(np.argmax(score))
     if found is not None:                                     # replay the returned path: it must solve the cube
         s = env.sim_cube[None].astype(np.uint8)
         for a in found:

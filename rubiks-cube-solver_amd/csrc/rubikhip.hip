@@ -4,15 +4,20 @@
 // Kernel map (DESIGN.md has the roofline of each):
 //   k_fill_solved     initState_3                      py333.py:211-218
 //   k_step            CubeEnv.step for N cubes          cube_env.py:71-111
-//                     (move + solved/reward + compact code, all in registers)
+//                     (move + solved/reward + compact code, all in registers; row traffic = raw buffer
+//                     instructions whose cache policy follows the working set, RowPolicy)
 //   k_step_dense      same + dense one-hot, the [slot][cube] code tile staged in LDS so the
 //                     [N][R][C] rows leave as coalesced 16-byte stores
 //   k_code_to_dense   compact code -> dense one-hot (same LDS stage)
 //   k_scramble        reset()'s scramble loop, in place    cube_env.py:65-67
+//   k_legacy_actions  numpy's legacy MT19937 draws of reset(seed, k), one env per lane    cube_env.py:62-65
 //   k_expand          12 children of every cube         cube_env.py:212-236, mcts.py:96-101
 //   k_adi             ADI walks + expansion, persistent over depth, per-walk xoroshiro128+
 //                                                       cube_env.py:177-194,212-236
 //   k_adi_targets     target value/policy/error         cube_env.py:229-232,239-251
+//   k_facade_step     CubeEnv.step / a whole move list for ONE cube, results into host-mapped memory
+//   k_facade_expand   key + 12 child keys + solved flags (+ dense one-hots) of ONE cube    mcts.py:83-113
+//   k_read_status     atomic read-and-clear of the per-device status word
 #include <hip/hip_runtime.h>
 
 #include <cstdio>

@@ -223,3 +223,52 @@ def test_adi_codes_default_dispatch_100k(ops, L, oracle):
     assert (untile(ops, bufs["child_code"], W, 2).transpose(2, 0, 1, 3) == exp["child_code"]).all()
     assert (bufs["child_solved"][..., :W].cpu().numpy().transpose(2, 0, 1) == exp["child_solved"]).all()
     assert L.read_status() == 0
+
+
+def _random_shapes(seed, count):
+    """Seeded ragged sizes around the places where the kernels change behaviour: pack width (4 / 8 cubes per lane), wave span
+    (256 / 512), tile boundaries (1024-cube tiles), single cubes."""
+    rng = np.random.default_rng(seed)
+    special = [1, 2, 3, 4, 5, 7, 8, 9, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2049, 4095, 4097]
+    out = []
+    for _ in range(count):
+        n = int(rng.choice(special)) if rng.random() < 0.5 else int(rng.integers(1, 9000))
+        pitch = None if n <= 1024 or rng.random() < 0.4 else int(rng.choice([1024, 2048, 4096]))
+        out.append((n, pitch, int(rng.choice([3, 2])), int(rng.choice([0, 1, 2])), int(rng.choice([0, 1, 2, 3, 6]))))
+    return out
+
+
+def test_randomised_ragged_sizes_all_kernels(ops, L, oracle):
+    """48 seeded (size, tiling, cube size, pack width, parts) combinations through step (+ code), expansion and ADI."""
+    for case, (n, pitch, cs, v, parts) in enumerate(_random_shapes(20260, 48)):
+        A = A_OF[cs]
+        tag = (case, n, pitch, cs, v, parts)
+        states = walk_states(oracle, cs, n, 9, seed=case)
+        acts = np.random.default_rng(case).integers(0, A, n, dtype=np.uint8)
+        exp_st, exp_code, exp_done, exp_rew = oracle.step(cs, states, acts)
+        src = ops.from_aos(states, "cuda", pitch)
+        dst = torch.zeros_like(src)
+        code = torch.zeros((src.shape[0], SL_OF[cs], src.shape[2]), dtype=torch.uint8, device="cuda")
+        rew = torch.zeros(n, dtype=torch.float32, device="cuda")
+        done = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        ops.apply_moves(src, dst, torch.from_numpy(acts).cuda(), n, cs, rew, done, code, L.FMT_CODE, variant=v)
+        assert (ops.to_aos(dst, n).cpu().numpy() == exp_st).all(), tag
+        assert (ops.to_aos(code, n).cpu().numpy() == exp_code).all(), tag
+        assert (done.cpu().numpy() == exp_done).all() and (rew.cpu().numpy() == exp_rew).all(), tag
+        ch, cc, cso = oracle.expand(cs, exp_st, threads=4)
+        out = ops.expand_buffers(n, cs, "cuda", src.shape[2], children=True, codes=True)
+        ops.expand_children(dst, n, cs, out["children"], out["child_solved"], out["child_code"], pitch=src.shape[2], variant=parts * 1000 + v)
+        assert (untile(ops, out["children"], n, 1).transpose(1, 0, 2) == ch).all(), tag
+        assert (untile(ops, out["child_code"], n, 1).transpose(1, 0, 2) == cc).all(), tag
+        assert (out["child_solved"][:, :n].cpu().numpy().T == cso).all(), tag
+        depth = 1 + case % 4
+        m = min(n, 3000)
+        adi_pitch = src.shape[2] if m > 1024 and pitch else L.pitch_for(m)
+        pt, bufs = ops.adi_buffers(m, depth, cs, "cuda", adi_pitch, parents=True, children=True, child_code=True, parent_code=True)
+        ops.adi_generate(m, depth, cs, pt, "cuda", seed=case, stream_id=7, walk_offset=case * 13, variant=parts * 1000 + v, **bufs)
+        ex = oracle.adi(cs, m, depth, seed=case, stream=7, walk0=case * 13, threads=4)
+        assert (untile(ops, bufs["children"], m, 2).transpose(2, 0, 1, 3) == ex["children"]).all(), tag
+        assert (untile(ops, bufs["child_code"], m, 2).transpose(2, 0, 1, 3) == ex["child_code"]).all(), tag
+        assert (untile(ops, bufs["parents"], m, 1).transpose(1, 0, 2) == ex["parents"]).all(), tag
+        assert (bufs["child_solved"][..., :m].cpu().numpy().transpose(2, 0, 1) == ex["child_solved"]).all(), tag
+    assert L.read_status() == 0

@@ -154,14 +154,14 @@ def test_adi_config3_full_size(ops, L, oracle):
     assert n_solved >= W                                                          # depth 1: the inverse move solves every walk
 
 
-@pytest.mark.parametrize("log2n", [20, 22])
-def test_apply_moves_full_batch_vs_oracle(ops, L, oracle, log2n):
-    """BASELINE config 2 (2^20 cubes) and the metric's batch (2^22): one rc_apply_moves launch with reward, done and the
-    compact code, default dispatch, compared with the oracle on ALL cubes (SURVEY 8d asks for >= 64 K)."""
-    cs, n = 3, 1 << log2n
+@pytest.mark.parametrize("cs,log2n", [(3, 20), (3, 22), (2, 22)])
+def test_apply_moves_full_batch_vs_oracle(ops, L, oracle, cs, log2n):
+    """BASELINE config 2 (2^20 cubes) and the metric's batch (2^22; also for 2x2x2): one rc_apply_moves launch with reward,
+    done and the compact code, default dispatch, compared with the oracle on ALL cubes (SURVEY 8d asks for >= 64 K)."""
+    n = 1 << log2n
     thr = oracle.max_threads()
     states = walk_states(oracle, cs, n, 20, seed=log2n, threads=thr)
-    acts = np.random.default_rng(log2n).integers(0, 12, n, dtype=np.uint8)
+    acts = np.random.default_rng(log2n).integers(0, A_OF[cs], n, dtype=np.uint8)
     k = 4096
     states[:k] = oracle.step(cs, oracle.solved(cs, k), (acts[:k] ^ 1))[0]         # these become solved again
     exp_st, exp_code, exp_done, exp_rew = oracle.step(cs, states, acts, threads=thr)

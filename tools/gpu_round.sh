@@ -15,9 +15,13 @@ python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "bench rc=$?
 cd /tmp && export TMPDIR=/tmp
 # (1) kernel trace + stats of the bench command itself (headline k_step and every config's kernel)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_stats -- python3 $R/bench.py --no-cpu --steps 200 --warmup 20 > $O/${TAG}_prof_stats.log 2>&1; echo "stats rc=$?"
-# (2) PMC passes, one counter group per run (FETCH_SIZE and WRITE_SIZE do not fit one pass)
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_prof_fetch -- python3 $R/bench.py --no-cpu --steps 10 --warmup 2 > $O/${TAG}_prof_fetch.log 2>&1; echo "fetch rc=$?"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_prof_write -- python3 $R/bench.py --no-cpu --steps 10 --warmup 2 > $O/${TAG}_prof_write.log 2>&1; echo "write rc=$?"
+# (2) PMC passes, one counter group per run (FETCH_SIZE and WRITE_SIZE do not fit one pass).  The traffic figure of the headline
+# kernel comes from runs WITHOUT the extra configs: they launch the same k_step instantiation with a reward array (+4 B per
+# cube), which would pollute the per-kernel mean.  A second WRITE_SIZE pass with the configs covers k_adi / k_expand / dense.
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_prof_fetch -- python3 $R/bench.py --no-cpu --no-configs --steps 10 --warmup 2 > $O/${TAG}_prof_fetch.log 2>&1; echo "fetch rc=$?"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_prof_write -- python3 $R/bench.py --no-cpu --no-configs --steps 10 --warmup 2 > $O/${TAG}_prof_write.log 2>&1; echo "write rc=$?"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_prof_writecfg -- python3 $R/bench.py --no-cpu --steps 10 --warmup 2 > $O/${TAG}_prof_writecfg.log 2>&1; echo "write (configs) rc=$?"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_prof_fetchcfg -- python3 $R/bench.py --no-cpu --steps 10 --warmup 2 > $O/${TAG}_prof_fetchcfg.log 2>&1; echo "fetch (configs) rc=$?"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES --output-format csv -d $O/${TAG}_prof_sq -- python3 $R/bench.py --no-cpu --steps 10 --warmup 2 > $O/${TAG}_prof_sq.log 2>&1; echo "sq rc=$?"
 # (3) the ADI kernel in FIVE fresh processes (placement-to-placement spread was 15 % in round 1)
 for i in 1 2 3 4 5; do

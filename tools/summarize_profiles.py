@@ -75,25 +75,36 @@ if fresh:
                "k_adi_frac_of_8TBps_per_process": [715 * W * D / (a * 1e-6) / 8e12 for a in avgs],
                "processes": fresh}, open(os.path.join(P, f"{rnd}_adi_fresh_processes.json"), "w"), indent=1)
 
-pmc = {}
-for name in ("fetch", "write", "sq"):
-    for f in glob.glob(os.path.join(G, f"{tag}_prof_{name}", "**", "*_counter_collection.csv"), recursive=True):
-        agg = collections.defaultdict(list)
-        for r in csv.DictReader(open(f)):
-            agg[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
-        for (k, c), v in agg.items():
-            pmc.setdefault(short(k), {})[c] = {"mean": sum(v) / len(v), "launches": len(v)}
-pmc = {k: v for k, v in pmc.items() if k.startswith("k_")}          # our kernels only (torch's GEMMs etc. are not the subject)
+def read_pmc(names):
+    out = {}
+    for name in names:
+        for f in glob.glob(os.path.join(G, f"{tag}_prof_{name}", "**", "*_counter_collection.csv"), recursive=True):
+            agg = collections.defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                agg[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+            for (k, c), v in agg.items():
+                out.setdefault(short(k), {})[c] = {"mean": sum(v) / len(v), "launches": len(v)}
+    return {k: v for k, v in out.items() if k.startswith("k_")}     # our kernels only (torch's GEMMs etc. are not the subject)
+
+
+headline = read_pmc(("fetch", "write"))            # bench.py --no-configs: only the headline launches of k_step
+pmc = read_pmc(("fetchcfg", "writecfg", "sq"))     # with the configs: k_adi, k_expand, dense kernels, ...
+HEAD = "k_step<rc::Cube3, 2, true, true, false, 1, 64>"
+if HEAD in headline:
+    pmc[HEAD + " [headline launches only]"] = headline[HEAD]
+    pmc.setdefault(HEAD, {})["note"] = ("means over the headline AND the reward-bearing config launches of the same instantiation (+4 B per cube on "
+                                        "some): use the [headline launches only] entry for the bench's roofline.traffic")
 if pmc:
     json.dump(pmc, open(os.path.join(P, f"{rnd}_pmc.json"), "w"), indent=1, sort_keys=True)
-step = [(k, v) for k, v in pmc.items() if k.startswith("k_step<rc::Cube3, 2, true, true, false, 1") and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
-if step:
-    k, s = max(step, key=lambda kv: kv[1]["FETCH_SIZE"]["launches"])
-    rd, wr = s["FETCH_SIZE"]["mean"] * 1024 * 2, s["WRITE_SIZE"]["mean"] * 1024
-    json.dump({"round": rnd, "kernel": k, "k_step_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
-               "note": "FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE KiB x 1024, separate --pmc passes, "
-                       "bench.py workload (2^22 cubes, move + done flag); algorithmic = 110 B x 2^22 = 461373440.  These are the L2's "
-                       "fabric-side request counters: Infinity-Cache hits are counted, so this is fabric traffic, an upper bound of DRAM traffic"},
+if HEAD in headline and "FETCH_SIZE" in headline[HEAD] and "WRITE_SIZE" in headline[HEAD]:
+    s_ = headline[HEAD]
+    rd, wr = s_["FETCH_SIZE"]["mean"] * 1024 * 2, s_["WRITE_SIZE"]["mean"] * 1024
+    json.dump({"round": rnd, "kernel": HEAD, "k_step_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
+               "launches_counted": {"FETCH_SIZE": s_["FETCH_SIZE"]["launches"], "WRITE_SIZE": s_["WRITE_SIZE"]["launches"]},
+               "note": "FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE KiB x 1024, separate --pmc passes over "
+                       "`python3 bench.py --no-cpu --no-configs --steps 10 --warmup 2` (2^22 cubes, move + done flag; the headline launches only); "
+                       "algorithmic = 110 B x 2^22 = 461373440.  These are the L2's fabric-side request counters: Infinity-Cache hits are counted, "
+                       "so this is fabric traffic, an upper bound of DRAM traffic"},
               open(os.path.join(P, "traffic.json"), "w"), indent=1)
 for k in sorted(pmc):
     print(k, {c: round(v["mean"], 1) for c, v in pmc[k].items() if c in ("FETCH_SIZE", "WRITE_SIZE")})

@@ -13,8 +13,10 @@ if [ "${SKIP_TESTS:-0}" != "1" ]; then
 fi
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "bench rc=$?"
 cd /tmp && export TMPDIR=/tmp
-# (1) kernel trace + stats of the bench command itself (headline k_step and every config's kernel)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_stats -- python3 $R/bench.py --no-cpu --steps 200 --warmup 20 > $O/${TAG}_prof_stats.log 2>&1; echo "stats rc=$?"
+# (1) kernel trace + stats of the bench command: the headline alone (its k_step average is the one roofline.launch_us must agree
+# with; the configs launch the same instantiation with a reward array), then with every config's kernel
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_stats -- python3 $R/bench.py --no-cpu --no-configs --steps 200 --warmup 20 > $O/${TAG}_prof_stats.log 2>&1; echo "stats rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_statscfg -- python3 $R/bench.py --no-cpu --steps 200 --warmup 20 > $O/${TAG}_prof_statscfg.log 2>&1; echo "stats (configs) rc=$?"
 # (2) PMC passes, one counter group per run (FETCH_SIZE and WRITE_SIZE do not fit one pass).  The traffic figure of the headline
 # kernel comes from runs WITHOUT the extra configs: they launch the same k_step instantiation with a reward array (+4 B per
 # cube), which would pollute the per-kernel mean.  A second WRITE_SIZE pass with the configs covers k_adi / k_expand / dense.

@@ -5,7 +5,8 @@
 
 Writes
   profiles/<round>_bench.json               the bench.py JSON line of the session
-  profiles/<round>_kernel_stats.csv         rocprofv3 --kernel-trace --stats of `python3 bench.py --no-cpu --steps 200 --warmup 20`
+  profiles/<round>_kernel_stats.csv         rocprofv3 --kernel-trace --stats of `python3 bench.py --no-cpu --no-configs --steps 200 --warmup 20`
+  profiles/<round>_kernel_stats_configs.csv the same with the configs (k_adi, k_expand, dense kernels, ...)
   profiles/<round>_pmc.json                 mean FETCH_SIZE / WRITE_SIZE / SQ counters per kernel (separate --pmc passes)
   profiles/<round>_adi_fresh_processes.json k_adi / k_expand averages of FIVE fresh processes (rocprofv3 kernel stats each)
   profiles/<round>_design_kernel_stats.csv  kernel-stat rows of the design A/B harness (tools/exp/exp_step2 22 0 1)
@@ -47,6 +48,9 @@ for name in ("bench", "cfg5", "rollout", "facade", "adi_pipeline"):
 stats = first(f"{tag}_prof_stats/**/*_kernel_stats.csv")
 if stats:
     shutil.copy(stats, os.path.join(P, f"{rnd}_kernel_stats.csv"))
+statscfg = first(f"{tag}_prof_statscfg/**/*_kernel_stats.csv")
+if statscfg:
+    shutil.copy(statscfg, os.path.join(P, f"{rnd}_kernel_stats_configs.csv"))
 design = first(f"{tag}_prof_design/**/*_kernel_stats.csv")
 if design:
     shutil.copy(design, os.path.join(P, f"{rnd}_design_kernel_stats.csv"))

@@ -1,23 +1,26 @@
 #!/usr/bin/env python3
 """Headline benchmark: cube-move steps/s, 3x3x3, batch 4M per GPU (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu] [--no-configs]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--cubes-per-gpu C] [--no-cpu] [--no-configs]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W [--cubes-per-gpu 1048576]
 
 One bench "step" = one pass of the hot path over one batch: ONE rc_apply_moves launch that moves
-2^22 cubes (each by its own random face turn) and writes their solved flags, ping-ponging two
-HBM-resident state buffers (working set 453 MB > the 256 MB Infinity Cache, so HBM-bound).
+C cubes per GPU (each by its own random face turn) and writes their solved flags, ping-ponging two
+HBM-resident state buffers.  C defaults to 2^22 (the metric's batch: working set 453 MB > the 256 MB Infinity
+Cache); --cubes-per-gpu 1048576 is BASELINE config 4's shape (1M cubes per GPU x N GPUs).
 Inputs are resident in HBM before the timed region.  value = cubes * K * N / max-over-ranks time.
 Every rank owns its own batch and RNG stream (stream_id = rank); there is no collective on the
-env path ("scaling": "weak").  One JSON line is printed by rank 0.
+env path ("scaling": "weak").  One JSON line is printed by rank 0; with N > 1 it carries `per_gpu` (each rank's stream_id,
+rate and a sha256 of its first 65536 scrambled cubes, which the tests compare with the oracle's (seed, rank) stream).
 
-At N = 1 the line also carries "configs": the other BASELINE.json workloads, each timed OUTSIDE the headline's timed
-region with HIP events on the launch stream and with a roofline sub-record of its own (kernel name, algorithmic
-bytes per launch, achieved GB/s, fraction of the 8 TB/s HBM peak): config 2 (1M cubes, move + reward + done), the
-step with the fused compact code and with the fused dense one-hot (f32 / bf16), config 3 (ADI 100k walks x 30,
-715 B per (walk, depth)), the 1M-parent expansion, config 5 (us per MCTS step, eager and as a hipGraph) and the
-batch-1 facade latency.  --no-configs skips them.
+The line also carries "configs" (rank 0, every N): the other BASELINE.json workloads, each timed OUTSIDE the headline's timed
+region with HIP events on the launch stream and with a roofline sub-record of its own (kernel = what the library's own
+dispatch reports, algorithmic bytes per launch, achieved GB/s, fraction of the 8 TB/s HBM peak): config 2 (1M cubes,
+move + reward + done), the 4M step in place, with the reward, with the fused compact code, the 16M-cube step whose 1.8 GB
+ping-pong defeats the Infinity Cache (the HBM-only point: roofline.frac_hbm_only), the fused dense one-hot (f32 / bf16),
+config 3 (ADI 100k walks x 30, 715 B per (walk, depth)), the 1M-parent expansion, config 5 (us per MCTS step, eager and
+as a hipGraph) and the batch-1 facade latency.  --no-configs skips them.
 """
 import argparse
 import json
@@ -130,8 +133,11 @@ def cpu_baseline(budget_s=8.0):
 
 def other_configs(torch, ops, _lib, dev, acts):
     """BASELINE.json configs 2, 3, 5 and the fused-output variants, each with its own roofline sub-record.
-    Timed with HIP events on the launch stream, outside the headline's timed region."""
+    Timed with HIP events on the launch stream, outside the headline's timed region.  `kernel` of every record is what
+    rc_describe_dispatch reports for exactly that call (the library's own pick_* functions), never a literal."""
     recs = []
+    D = _lib.describe
+    ST, CODE, FLAGS, REW, INPL = _lib.OUT_STATES | _lib.OUT_DONE, _lib.OUT_CODE, _lib.OUT_FLAGS, _lib.OUT_REWARD, _lib.OUT_INPLACE
 
     def timed(fn, iters, warm=5):
         for _ in range(warm):
@@ -153,30 +159,49 @@ def other_configs(torch, ops, _lib, dev, acts):
         if note:
             r["note"] = note
         recs.append(r)
+        return r
 
     m = 1 << 20
-    rew = torch.empty(N_CUBES, dtype=torch.float32, device=dev)
-    done = torch.empty(N_CUBES, dtype=torch.uint8, device=dev)
+    n = N_CUBES
+    acts = acts[:n] if acts.numel() >= n else torch.randint(0, 12, (n,), device=dev, dtype=torch.uint8)
+    rew = torch.empty(n, dtype=torch.float32, device=dev)
+    done = torch.empty(n, dtype=torch.uint8, device=dev)
     # config 2: batch 1M, single apply_move + reward (+ done) -- the 113 MB ping-pong working set sits in the Infinity Cache
     a1, b1 = ops.alloc_states(m, CUBE, dev), ops.alloc_states(m, CUBE, dev)
     ops.fill_solved(a1, m, CUBE)
     ops.scramble(a1, m, CUBE, 20, seed=1234)
     pp = [a1, b1]
     t = timed(lambda: (ops.apply_moves(pp[0], pp[1], acts, m, CUBE, rew, done), pp.reverse()), 200)
-    rec("config 2: 3x3x3 batch 1M, apply_move + reward + done", "k_step<Cube3,2,move,store>", m, "steps", 114, t,
+    rec("config 2: 3x3x3 batch 1M, apply_move + reward + done", D(_lib.OP_STEP, CUBE, m, outputs=ST | REW), m, "steps", 114, t,
         "working set 113 MB: served from the 256 MB Infinity Cache, not HBM")
-    # the metric's batch with the reward and with the fused compact one-hot code
-    n = N_CUBES
+    # the metric's batch: in place, with the reward, with the fused compact one-hot code
     a4, b4 = ops.alloc_states(n, CUBE, dev), ops.alloc_states(n, CUBE, dev)
     ops.fill_solved(a4, n, CUBE)
     ops.scramble(a4, n, CUBE, 20, seed=1234)
     p4 = [a4, b4]
+    t = timed(lambda: ops.apply_moves(a4, a4, acts, n, CUBE, None, done), 50)
+    rec("3x3x3 batch 4M, apply_move + done IN PLACE (what VecCubeEnv.step launches; 226 MB working set)", D(_lib.OP_STEP, CUBE, n, outputs=ST | INPL),
+        n, "steps", 110, t, "one buffer read and rewritten: the working set fits the Infinity Cache")
     t = timed(lambda: (ops.apply_moves(p4[0], p4[1], acts, n, CUBE, rew, done), p4.reverse()), 50)
-    rec("3x3x3 batch 4M, apply_move + reward + done", "k_step<Cube3,2,move,store>", n, "steps", 114, t)
+    rec("3x3x3 batch 4M, apply_move + reward + done", D(_lib.OP_STEP, CUBE, n, outputs=ST | REW), n, "steps", 114, t)
     code = ops.alloc_code(n, CUBE, dev)
     t = timed(lambda: (ops.apply_moves(p4[0], p4[1], acts, n, CUBE, rew, done, code, _lib.FMT_CODE), p4.reverse()), 50)
-    rec("3x3x3 batch 4M, apply_move + reward + done + fused compact one-hot code (20 B)", "k_step<Cube3,2,move,store,code>", n, "steps", 134, t)
+    rec("3x3x3 batch 4M, apply_move + reward + done + fused compact one-hot code (20 B)", D(_lib.OP_STEP, CUBE, n, outputs=ST | REW | CODE, fmt=_lib.FMT_CODE),
+        n, "steps", 134, t)
     del code, a4, b4, p4
+    # the HBM-only point: 2^24 cubes, 1.8 GB ping-pong -- nothing of it survives in the 256 MB Infinity Cache between launches
+    n16 = 1 << 24
+    a16, b16 = ops.alloc_states(n16, CUBE, dev), ops.alloc_states(n16, CUBE, dev)
+    ops.fill_solved(a16, n16, CUBE)
+    ops.scramble(a16, n16, CUBE, 20, seed=1234)
+    acts16 = acts.repeat(n16 // n)
+    done16 = torch.empty(n16, dtype=torch.uint8, device=dev)
+    p16 = [a16, b16]
+    t = timed(lambda: (ops.apply_moves(p16[0], p16[1], acts16, n16, CUBE, None, done16), p16.reverse()), 20, 3)
+    hbm_only = rec("3x3x3 batch 16M, apply_move + done, nothing cached (1.8 GB ping-pong: the HBM-only point)", D(_lib.OP_STEP, CUBE, n16, outputs=ST),
+                   n16, "steps", 110, t, "inputs and outputs streamed (nt / sc0 sc1 nt): every byte comes from and goes to HBM")
+    del a16, b16, p16, acts16, done16
+    torch.cuda.empty_cache()
     # 2x2x2 (24 stickers, 6 actions): 24 R + 24 W + 1 + 1 = 50 B per step
     a2, b2 = ops.alloc_states(n, 2, dev), ops.alloc_states(n, 2, dev)
     ops.fill_solved(a2, n, 2)
@@ -184,34 +209,34 @@ def other_configs(torch, ops, _lib, dev, acts):
     acts2 = acts % 6
     p2 = [a2, b2]
     t = timed(lambda: (ops.apply_moves(p2[0], p2[1], acts2, n, 2, None, done), p2.reverse()), 100)
-    rec("2x2x2 batch 4M, apply_move + done (201 MB ping-pong: Infinity-Cache resident)", "k_step<Cube2,2,move,store>", n, "steps", 50, t)
+    rec("2x2x2 batch 4M, apply_move + done (201 MB ping-pong: Infinity-Cache resident)", D(_lib.OP_STEP, 2, n, outputs=ST), n, "steps", 50, t)
     del a2, b2, p2, acts2
     # fused dense one-hot in the layout model.py consumes
     for dt, fmt, name, bpc in ((torch.float32, _lib.FMT_F32, "f32", 1920), (torch.bfloat16, _lib.FMT_BF16, "bf16", 960)):
         oh = torch.empty((m, 20, 24), dtype=dt, device=dev)
         t = timed(lambda: ops.apply_moves(a1, b1, acts, m, CUBE, rew, done, oh, fmt), 10, 2)
-        rec(f"3x3x3 batch 1M, apply_move + reward + done + fused dense {name} one-hot [N,20,24]", f"k_step_dense<Cube3,{name},256>", m, "steps",
+        rec(f"3x3x3 batch 1M, apply_move + reward + done + fused dense {name} one-hot [N,20,24]", D(_lib.OP_STEP, CUBE, m, outputs=ST | REW, fmt=fmt), m, "steps",
             114 + bpc, t)
         del oh
     # 1M-parent expansion (the MCTS / ADI child loop at scale)
     ex = ops.expand_buffers(m, CUBE, dev, children=True, codes=False)
     t = timed(lambda: ops.expand_children(a1, m, CUBE, ex["children"], ex["child_solved"], pitch=ex["children"].shape[-1]), 30)
-    rec("3x3x3 expansion of 1M parents to all 12 children + solved flags", "k_expand<Cube3,2>", m, "parents", 54 + 12 * 54 + 12, t)
+    rec("3x3x3 expansion of 1M parents to all 12 children + solved flags", D(_lib.OP_EXPAND, CUBE, m, outputs=ST | FLAGS), m, "parents", 54 + 12 * 54 + 12, t)
     del ex, a1, b1, pp
     # config 3: ADI data generation
-    W, D = 100_000, 30
-    pt, ab = ops.adi_buffers(W, D, CUBE, dev, parents=True, children=True)
-    t = timed(lambda: ops.adi_generate(W, D, CUBE, pt, dev, seed=2024, **ab), 10, 3)
-    rec("config 3: ADI 100k walks x depth 30, parents + 12 children + flags + actions", "k_adi<Cube3,2>", W * D, "walk-depths", 715, t,
-        f"{13 * W * D / t:.4g} cube-move steps/s; output tiles of {pt} walks; 0 bytes read")
+    W, DEPTH = 100_000, 30
+    pt, ab = ops.adi_buffers(W, DEPTH, CUBE, dev, parents=True, children=True)
+    t = timed(lambda: ops.adi_generate(W, DEPTH, CUBE, pt, dev, seed=2024, **ab), 10, 3)
+    rec("config 3: ADI 100k walks x depth 30, parents + 12 children + flags + actions", D(_lib.OP_ADI, CUBE, W, DEPTH, outputs=ST | FLAGS), W * DEPTH, "walk-depths", 715, t,
+        f"{13 * W * DEPTH / t:.4g} cube-move steps/s; output tiles of {pt} walks; 0 bytes read")
     del ab
-    pt, ab = ops.adi_buffers(W, D, CUBE, dev, parents=True, parent_code=True, child_code=True)
-    t = timed(lambda: ops.adi_generate(W, D, CUBE, pt, dev, seed=2024, **ab), 10, 3)
-    rec("ADI 100k x 30 with compact codes instead of child stickers", "k_adi<Cube3,1,code>", W * D, "walk-depths", 54 + 1 + 12 + 13 * 20, t,
-        "VALU-bound (13 x 20 code look-ups per unit), not a bandwidth figure", bound="valu")
+    pt, ab = ops.adi_buffers(W, DEPTH, CUBE, dev, **ADI_CODE_OUTPUTS)
+    t = timed(lambda: ops.adi_generate(W, DEPTH, CUBE, pt, dev, seed=2024, **ab), 10, 3)
+    rec("ADI 100k x 30 with compact codes instead of child stickers (parent stickers + 13 codes + flags + actions)", D(_lib.OP_ADI, CUBE, W, DEPTH, outputs=CODE | FLAGS),
+        W * DEPTH, "walk-depths", 54 + 1 + 12 + 13 * 20, t, f"output tiles of {pt} walks")
     del ab
     torch.cuda.empty_cache()
-    out = {"records": recs}
+    out = {"records": recs, "hbm_only_frac": hbm_only["roofline"]["frac"]}
     try:                                                           # config 5 (latency-bound: microseconds, not GB/s)
         from tools.bench_cfg5 import run as cfg5
         r5 = cfg5(short=True)
@@ -237,17 +262,28 @@ def other_configs(torch, ops, _lib, dev, acts):
     return out
 
 
+ADI_CODE_OUTPUTS = dict(parents=True, parent_code=True, child_code=True)
+SAMPLE_CUBES = 1 << 16      # per-rank sample whose sha256 the N>1 line carries (tests replay it through the oracle)
+SCRAMBLE_SEED, SCRAMBLE_DEPTH = 1234, 20
+
+
 def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before anything initialises the HIP runtime (RCCL / IPC, N > 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--cubes-per-gpu", type=int, default=N_CUBES,
+                    help="batch per GPU (default 2^22 = the metric's batch; 1048576 = BASELINE config 4: 1M cubes per GPU x N GPUs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs (timed outside the headline region)")
     ap.add_argument("--extras", action="store_true", help="(kept for compatibility: the configs are on by default)")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
+    if args.cubes_per_gpu < 1:
+        sys.exit("--cubes-per-gpu must be positive")
+
+    import hashlib
 
     import torch
     import torch.distributed as dist
@@ -270,12 +306,16 @@ def main():
             dist.init_process_group(args.backend)
 
     from rubiks_cube_solver_amd import _lib, ops  # raises if librubikhip.so is missing: no fallback
+    from rubiks_cube_solver_amd import dist as rcdist
 
-    n = N_CUBES
+    n = args.cubes_per_gpu
+    stream_id = rcdist.rng_stream(rank)                              # rank-distinct RNG stream, no exchange between ranks
     a = ops.alloc_states(n, CUBE, dev)
     b = torch.empty_like(a)
     ops.fill_solved(a, n, CUBE)
-    ops.scramble(a, n, CUBE, 20, seed=1234, stream_id=rank)         # 20-move scrambles, rank-distinct streams
+    ops.scramble(a, n, CUBE, SCRAMBLE_DEPTH, seed=SCRAMBLE_SEED, stream_id=stream_id)   # 20-move scrambles, rank-distinct streams
+    k = min(n, SAMPLE_CUBES)
+    sample_sha = hashlib.sha256(ops.to_aos(a, k).contiguous().cpu().numpy().tobytes()).hexdigest()
     g = torch.Generator(device=dev).manual_seed(1 + rank)
     acts = torch.randint(0, 12, (n,), generator=g, device=dev, dtype=torch.uint8)
     done = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -308,8 +348,12 @@ def main():
         t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)                                     # reporting only: per-GPU figures beside the aggregate (config 4)
-        per_rank = [{"rank": r, "ms_per_step": float(x[0]) / args.steps * 1e3, "launch_us": float(x[1]) / args.steps * 1e3,
-                     "steps_per_s": n * args.steps / float(x[0]), "GBps": BYTES_PER_STEP * n / (float(x[1]) * 1e-3 / args.steps) / 1e9}
+        shas = [None] * world
+        dist.all_gather_object(shas, {"stream_id": stream_id, "sha": sample_sha, "device": torch.cuda.get_device_name(dev_index)})
+        per_rank = [{"rank": r, "stream_id": shas[r]["stream_id"], "ms_per_step": float(x[0]) / args.steps * 1e3,
+                     "launch_us": float(x[1]) / args.steps * 1e3, "steps_per_s": n * args.steps / float(x[0]),
+                     "GBps": BYTES_PER_STEP * n / (float(x[1]) * 1e-3 / args.steps) / 1e9,
+                     "initial_state_sha256_first_cubes": shas[r]["sha"], "sha_cubes": k}
                     for r, x in enumerate(every)]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dev_ms = float(t[0]), float(t[1])
@@ -326,8 +370,9 @@ def main():
         c1.record()
         torch.cuda.synchronize()
         copy_gbps = 2 * bufs[0].numel() / (c0.elapsed_time(c1) / 20 * 1e-3) / 1e9
+    kernel = _lib.describe(_lib.OP_STEP, CUBE, n, outputs=_lib.OUT_STATES | _lib.OUT_DONE)   # what the headline launches, from the library's own dispatch
     configs = None
-    if rank == 0 and world == 1 and not args.no_configs:
+    if rank == 0 and not args.no_configs:
         del a, b, bufs
         torch.cuda.empty_cache()
         configs = other_configs(torch, ops, _lib, dev, acts)
@@ -339,7 +384,7 @@ def main():
         achieved = BYTES_PER_STEP * n / launch_s / 1e9
         traffic, traffic_source = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-derived bytes per launch, if profiled
-        if os.path.exists(tfile):
+        if os.path.exists(tfile) and n == N_CUBES:
             try:
                 tj = json.load(open(tfile))
                 traffic = tj.get("k_step_bytes_per_launch")
@@ -347,23 +392,34 @@ def main():
                                   "over this same command (not re-measured in this run)")
             except Exception:
                 traffic = None
+        state_mb = n * 54 / 1e6
+        pol = kernel.split("POL=")[1][0] if "POL=" in kernel else "?"
+        served = {"0": f"working set {2 * state_mb:.0f} MB fits the 256 MB Infinity Cache: rows default-cached, served on-die, NOT an HBM figure",
+                  "1": "input rows streamed (nt), output rows written through and kept (sc0 sc1): the next launch finds part of its input in the "
+                       "256 MB Infinity Cache, so DRAM traffic is below the fabric traffic the counters show; the nothing-cached figure is "
+                       "roofline.frac_hbm_only",
+                  "2": "input rows streamed (nt), output rows streamed (sc0 sc1 nt): every byte comes from and goes to HBM"}.get(pol, "")
+        workload = (f"3x3x3 apply_move + solved flag, {n} cubes per GPU per launch x {world} GPU(s), uint8 SoA [54][N] in 32768-cube tiles, "
+                    "ping-pong of two buffers; ")
+        workload += ("configs[1] shape at the metric's batch 4M" if n == N_CUBES else
+                     "BASELINE configs[3] shape: 1M cubes per GPU, rank-distinct RNG streams, no collective" if n == 1 << 20 else "custom batch")
         out = {
             "metric": "cube-move steps/sec, 3x3x3 batch 4M; HBM GB/s vs roofline at 1/2/4/8 GPU",
             "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "3x3x3 apply_move + solved flag, 2^22 cubes per GPU per launch, uint8 SoA [54][N], "
-                                   "ping-pong of two buffers (configs[1] shape at the metric's batch 4M)",
-                       "cubes_per_gpu": n, "bytes_per_step_algorithmic": BYTES_PER_STEP,
-                       "parallelism": f"{world} independent ranks, no collective"},
+            "config": {"workload": workload, "cubes_per_gpu": n, "total_cubes": n * world, "bytes_per_step_algorithmic": BYTES_PER_STEP,
+                       "parallelism": f"{world} independent ranks, stream_id = rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "k_step<Cube3,2,move,store,POL1>", "launch_us": launch_s * 1e6,
+                         "kernel": kernel, "launch_us": launch_s * 1e6,
                          "algorithmic_bytes_per_launch": BYTES_PER_STEP * n,
+                         "served_by": "hbm" if pol == "2" else "hbm + infinity cache" if pol == "1" else "infinity cache",
+                         "frac_hbm_only": configs["hbm_only_frac"] if configs else None,
+                         "frac_hbm_only_note": "the same kernel at 2^24 cubes (1.8 GB ping-pong, nothing cached): configs.records, 'HBM-only point'",
                          "device_copy_GBps": copy_gbps, "frac_of_device_copy": achieved / copy_gbps if copy_gbps else None,
-                         "device_copy_note": "hipMemcpy D2D (torch copy_) of the same 226 MB state buffer, read + write bytes",
-                         "note": "input rows streamed (nt), output rows written through and kept (sc0 sc1): the next launch finds part of "
-                                 "its input in the 256 MB Infinity Cache, so DRAM traffic is below the fabric traffic the counters show"},
+                         "device_copy_note": f"hipMemcpy D2D (torch copy_) of the same {state_mb:.0f} MB state buffer, read + write bytes",
+                         "note": served},
         }
         if per_rank:
             out["per_gpu"] = per_rank

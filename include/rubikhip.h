@@ -13,7 +13,7 @@
  *     (cube_size 3) or 24 (cube_size 2) rows, in TILES of `pitch` cubes:
  *         sticker s of cube n lives at st[(n / pitch) * S * pitch + s * pitch + n % pitch].
  *     One tile (pitch >= n_cubes, pitch % 16 == 0) is plain SoA, st[s * pitch + n].  Several
- *     tiles need a power-of-two pitch >= 1024; 16384-32768 measured best on MI355X at 4M cubes
+ *     tiles need a power-of-two pitch >= 512 (the widest wave span); 16384-32768 measured best on MI355X at 4M cubes
  *     (+12..24 % HBM throughput over one 4M-wide tile: every wave's 54 row segments then sit
  *     within 54 * pitch bytes).  RC_FMT_CODE buffers are tiled the same way with SLOTS rows.
  *     Buffers described as "plain" below are one tile.  Base pointers are 16-byte aligned.
@@ -109,7 +109,8 @@ int rc_apply_moves_ex(const uint8_t *in, uint8_t *out, const uint8_t *actions, i
  * st is a device state buffer whose cube 0 is stepped in place (sticker s at st[s * pitch]); the action
  * travels by value; the kernel writes into `host_out`, 512 bytes of HOST-MAPPED pinned memory
  * (hipHostMalloc / torch pin_memory): [0, R*C) the dense uint8 one-hot of the new state, [496] done,
- * [504..507] `seq` (non-zero, written last after a system-scope fence).  wait != 0: returns once `seq`
+ * [504..507] `seq` (non-zero, written last after a system-scope fence).  The kernel writes through the buffer's DEVICE alias
+ * (hipPointerGetAttributes), the host polls the host address, so hipHostRegister'ed memory works too.  wait != 0: returns once `seq`
  * is visible in host_out (spin on the flag; no stream synchronisation, no copies); wait == 0: returns
  * after the launch and the caller polls host_out itself.  Out-of-range actions set RC_STATUS_BAD_ACTION. */
 int rc_facade_step(uint8_t *st, int64_t pitch, int cube_size, int action, uint8_t *host_out,
@@ -128,6 +129,10 @@ int rc_facade_steps(uint8_t *st, int64_t pitch, int cube_size, const uint8_t *ac
  * and with dense != 0 [512 + a * R*C, ...) the dense uint8 one-hot of child a. */
 int rc_facade_expand(const uint8_t *st, int64_t pitch, int cube_size, uint8_t *host_out, uint32_t seq,
                      int dense, int wait, void *stream);
+
+/* The facade entry points cache, per calling thread, the device alias of the last host_out they validated.  Call this before
+ * freeing a host_out buffer whose address could be reused by memory that is not host-mapped (NULL drops whatever is cached). */
+int rc_facade_release(const uint8_t *host_out);
 
 /* `depth` moves applied in place to every cube: the scramble loop of CubeEnv.reset
  * (cube_env.py:65-67) for n_cubes cubes at once.  actions_in[d * act_pitch + n] replays given
@@ -181,7 +186,7 @@ int rc_expand_children_ex(const uint8_t *in, int64_t n_cubes, int64_t pitch_in, 
  *                uses xoroshiro128+ seeded by splitmix64 from (seed, stream_id, walk)
  *                (DESIGN.md "RNG"); non-NULL: replay actions_in[d * pitch + w].
  * Layouts, with tiles = ceil(n_walks / pitch) when n_walks > pitch (then pitch is a power of two
- * >= 1024), else 1, and Wp = tiles * pitch (any pointer may be NULL to skip that output):
+ * >= 512), else 1, and Wp = tiles * pitch (any pointer may be NULL to skip that output):
  *   actions_in / actions_out  [depth][Wp]
  *   parents      [depth][tiles][S][pitch]          one tiled state buffer per depth
  *   parent_code  [depth][tiles][SLOTS][pitch]
@@ -214,6 +219,27 @@ int rc_adi_targets(const float *child_value, const uint8_t *child_solved, const 
  * that is still running on another stream is not lost -- it shows up in a later read. */
 int rc_read_status(uint32_t *status, void *stream);
 
+/* Which kernel instantiation and launch geometry a call WOULD use, as text (e.g. "k_step<Cube3,V=2,move,store,POL=1>
+ * grid=8192 block=64"), decided by the same host functions the launchers call: benchmarks label their records with it.
+ *   op       RC_OP_STEP (rc_apply_moves / rc_is_solved / rc_encode), RC_OP_EXPAND, RC_OP_ADI, RC_OP_CODE_TO_DENSE
+ *   n        cubes / parents / walks;  depth: RC_OP_ADI only
+ *   outputs  RC_OUT_* bits: STATES = the out buffer of a step (move + store) or the children stickers, CODE = compact codes,
+ *            FLAGS = child_solved, REWARD / DONE = the step's reward / done arrays, INPLACE = out aliases in (step)
+ *   fmt      the one-hot format of a step / code-to-dense call;  variant: the tuning override (0 = defaults)
+ * Nothing is launched; no reference counterpart (tooling). */
+#define RC_OP_STEP 1
+#define RC_OP_EXPAND 2
+#define RC_OP_ADI 3
+#define RC_OP_CODE_TO_DENSE 4
+#define RC_OUT_STATES 1u
+#define RC_OUT_CODE 2u
+#define RC_OUT_FLAGS 4u
+#define RC_OUT_REWARD 8u
+#define RC_OUT_INPLACE 16u
+#define RC_OUT_DONE 32u
+int rc_describe_dispatch(int op, int cube_size, int64_t n, int depth, unsigned outputs, int fmt, int variant,
+                         char *buf, int buflen);
+
 /* Message of the calling thread's last failed call ("" if none). */
 const char *rc_last_error(void);
 
@@ -221,9 +247,10 @@ const char *rc_last_error(void);
  * instantiation; there is NO process-global knob).  0 = the measured defaults.  Decimal digits:
  *   units      pack width: 1,2 -> 4,8 cubes per lane
  *   tens       row-traffic policy of the step kernel: 1 stream in / stream out, 2 default-cached,
- *              3 stream in / keep the output in the Infinity Cache
+ *              3 stream in / keep the output in the Infinity Cache, 4 state default-cached / side outputs streamed
  *   thousands  (2 digits) parts per walk group for expansion / ADI (1..A, rounded up to a divisor of A)
- *   100000s    dense one-hot tile: 1 -> 64, 2 -> 256 cubes per workgroup */
+ *   100000s    dense one-hot tile: 1 -> 64, 2 -> 256 cubes per workgroup
+ *   millions   (2 digits) depth segments per walk group of the ADI kernel (1..16, clamped to depth) */
 
 #ifdef __cplusplus
 }

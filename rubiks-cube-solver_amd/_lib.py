@@ -51,9 +51,12 @@ def _declare(L):
     L.rc_adi_generate_ex.argtypes = [u64, u64, i64, i64, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32]
     L.rc_adi_targets.argtypes = [vp, vp, vp, vp, i64, i64, i32, vp, vp, vp, vp]
     L.rc_read_status.argtypes = [vp, vp]
+    L.rc_describe_dispatch.argtypes = [i32, i32, i64, i32, ctypes.c_uint32, i32, i32, ctypes.c_char_p, i32]
+    L.rc_facade_release.argtypes = [vp]
     for name in ("rc_init", "rc_get_tables", "rc_fill_solved", "rc_apply_moves", "rc_apply_moves_ex", "rc_facade_step", "rc_facade_steps", "rc_facade_expand", "rc_scramble",
                  "rc_legacy_scramble_actions", "rc_is_solved", "rc_encode", "rc_onehot_from_code", "rc_expand_children",
-                 "rc_expand_children_ex", "rc_adi_generate", "rc_adi_generate_ex", "rc_adi_targets", "rc_read_status"):
+                 "rc_expand_children_ex", "rc_adi_generate", "rc_adi_generate_ex", "rc_adi_targets", "rc_read_status",
+                 "rc_describe_dispatch", "rc_facade_release"):
         getattr(L, name).restype = i32
 
 
@@ -122,6 +125,18 @@ def read_status(device=None) -> int:
     out = ctypes.c_uint32(0)
     check(lib().rc_read_status(ctypes.byref(out), stream_ptr(device)))
     return out.value
+
+
+OP_STEP, OP_EXPAND, OP_ADI, OP_CODE_TO_DENSE = 1, 2, 3, 4
+OUT_STATES, OUT_CODE, OUT_FLAGS, OUT_REWARD, OUT_INPLACE, OUT_DONE = 1, 2, 4, 8, 16, 32
+
+
+def describe(op, cube_size, n, depth=0, outputs=0, fmt=FMT_NONE, variant=0) -> str:
+    """The kernel instantiation + launch geometry a call WOULD use (rc_describe_dispatch): the library's own dispatch
+    functions decide, nothing is launched.  Works without a GPU."""
+    buf = ctypes.create_string_buffer(160)
+    check(lib().rc_describe_dispatch(op, cube_size, n, depth, outputs, fmt, variant, buf, len(buf)))
+    return buf.value.decode()
 
 
 def get_tables(cube_size):

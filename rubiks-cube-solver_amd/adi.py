@@ -22,7 +22,7 @@ from .tables import get_env_config
 
 @torch.no_grad()
 def adi_samples(model, cube_size, n_walks, depth, temperature, device="cuda", model_device=None, actions=None,
-                seed=0, stream_id=0, walk_offset=0, dense_budget_bytes=1 << 30, want_state_dense=False):
+                seed=0, stream_id=0, walk_offset=0, dense_budget_bytes=1 << 30, want_state_dense=False, dense_dtype=None):
     """Generate n_walks x depth ADI samples.  Returns a dict of tensors on `device`, walk-major:
 
         state_code     uint8   [W, D, SLOTS]   compact one-hot code of the sample state
@@ -34,12 +34,16 @@ def adi_samples(model, cube_size, n_walks, depth, temperature, device="cuda", mo
         actions        uint8   [W, D]          the move that led to the sample state
 
     actions: optional uint8 [W, D] moves to replay (e.g. the host's legacy numpy draws, which makes
-    the samples those of the reference for the same global seed); None draws on the device."""
+    the samples those of the reference for the same global seed); None draws on the device.
+    dense_dtype: dtype of the one-hot stream fed to `model` (default: float32, or the dtype of the model's first floating-point
+    parameter when that is bfloat16 / float16); the returned values are float32 either way."""
     dev = torch.device(device)
     (R, C), A = get_env_config(cube_size)
     SL = ops.N_SLOTS[cube_size]
     mdev = torch.device(model_device) if model_device is not None else _module_device(model, dev)
-    per_walk = (A + 1) * R * C * 4
+    # the dense stream is written in the dtype the net computes in (bf16 / f16 halve the 13 * p * 480 elements per depth)
+    ddtype = _module_dtype(model) if dense_dtype is None else dense_dtype
+    per_walk = (A + 1) * R * C * torch.empty((), dtype=ddtype).element_size()
     chunk = max(1, min(n_walks, dense_budget_bytes // per_walk))
     chunk = min(n_walks, max(1024, chunk // 1024 * 1024)) if n_walks > 1024 else n_walks
     weights = [float(d) ** (-1 * temperature) for d in range(1, depth + 1)]  # cube_env.py:247, Python pow
@@ -62,7 +66,7 @@ def adi_samples(model, cube_size, n_walks, depth, temperature, device="cuda", mo
             a_in = a_host.to(dev)
         ops.adi_generate(wc, depth, cube_size, pitch, dev, seed=seed, stream_id=stream_id, walk_offset=walk_offset + w0,
                          actions_in=a_in, **bufs)
-        dense = torch.empty(((A + 1) * p, R, C), dtype=torch.float32, device=dev)      # A child blocks + the parents
+        dense = torch.empty(((A + 1) * p, R, C), dtype=ddtype, device=dev)             # A child blocks + the parents
         tv = torch.empty((depth, wc), dtype=torch.float32, device=dev)
         tp = torch.empty((depth, wc), dtype=torch.int32, device=dev)
         err = torch.empty((depth, wc), dtype=torch.float64, device=dev)
@@ -92,6 +96,18 @@ def adi_samples(model, cube_size, n_walks, depth, temperature, device="cuda", mo
 def _lib_status(dev):
     if _lib.read_status(dev) & _lib.STATUS_BAD_ACTION:
         raise IndexError("action out of range")  # cube_env.py:86,96
+
+
+def _module_dtype(model):
+    try:
+        for prm in model.parameters():
+            if prm.dtype in (torch.bfloat16, torch.float16):
+                return prm.dtype
+            if prm.is_floating_point():
+                return torch.float32
+    except (AttributeError, TypeError):
+        pass
+    return torch.float32
 
 
 def _module_device(model, default):

@@ -543,8 +543,16 @@ __device__ __forceinline__ void dense_write_333(const uint8_t *lds_code, int tp,
 #pragma unroll
                 for (int j = 0; j < 4; ++j) u.d[j] = d == (uint32_t)j ? One<E>::v : 0u;
             } else {
+#ifdef RC_DENSE_CMP    // round 2's form: eight compares + eight selects + four ORs per 16-byte chunk
 #pragma unroll
                 for (int j = 0; j < 4; ++j) u.d[j] = (d == (uint32_t)(2 * j) ? One<E>::v : 0u) | (d == (uint32_t)(2 * j + 1) ? One<E>::v << 16 : 0u);
+#else                  // the 1 sits in element d of 8: one 64-bit shift gives the half it falls into, two compares pick the half
+                const uint64_t x = (uint64_t)One<E>::v << ((d & 3u) << 4);
+                const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+                const bool lo_half = d < 4u, hi_half = d - 4u < 4u;
+                u.d[0] = lo_half ? xl : 0u; u.d[1] = lo_half ? xh : 0u;
+                u.d[2] = hi_half ? xl : 0u; u.d[3] = hi_half ? xh : 0u;
+#endif
             }
             bst<4, kAuxStreamStore>(srd, off, 0, u);
         }

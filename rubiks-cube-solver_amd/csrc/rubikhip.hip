@@ -20,6 +20,7 @@
 //   k_read_status     atomic read-and-clear of the per-device status word
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 
@@ -43,7 +44,7 @@ __device__ uint32_t g_status;  // RC_STATUS_* bits, per device (one code object 
 // with `rows` rows lives in tile n / pitch; tiles follow each other, [tile][row][pitch].
 // `shift` = log2(pitch) when the buffer has several tiles, 63 when it has one (then tile = 0 and
 // any pitch % 16 == 0 works).  g0 is a wave-uniform cube index that is a multiple of the wave's
-// span (<= 1024 cubes), so a wave never straddles tiles (multi-tile pitch is a multiple of 1024).
+// span (<= 512 cubes: 8 per lane at most), so a wave never straddles tiles (multi-tile pitch is a multiple of 512 = kMinTile).
 __device__ __forceinline__ int64_t tile_off(int64_t g0, int64_t pitch, int shift, int rows) {
     return g0 + (g0 >> shift) * (rows - 1) * pitch;
 }
@@ -51,13 +52,13 @@ __device__ __forceinline__ int64_t tile_off(int64_t g0, int64_t pitch, int shift
 // ------------------------------------------------------------------------------ fill
 template <class T>
 __global__ void __launch_bounds__(kWave) k_fill_solved(uint8_t *base, int64_t n, int64_t pitch, int shift) {
-    const int64_t g0 = (int64_t)blockIdx.x * (kWave * 16);
-    const uint32_t lo = threadIdx.x * 16;
+    const int64_t g0 = (int64_t)blockIdx.x * (kWave * 8);      // wave span 512 cubes = the smallest tile
+    const uint32_t lo = threadIdx.x * 8;
     if (g0 + lo >= n) return;
     const __amdgpu_buffer_rsrc_t r = make_srd(base + tile_off(g0, pitch, shift, T::S));
     const uint32_t rs = (uint32_t)pitch;
 #pragma unroll
-    for (int s = 0; s < T::S; ++s) bst<4, kAuxCached>(r, lo, s * rs, splat<4>((uint32_t)(s / T::FACE) * 0x01010101u));
+    for (int s = 0; s < T::S; ++s) bst<2, kAuxCached>(r, lo, s * rs, splat<2>((uint32_t)(s / T::FACE) * 0x01010101u));
 }
 
 // ------------------------------------------------------------------------------ step
@@ -92,11 +93,19 @@ __device__ __forceinline__ void store_reward(float *reward, int64_t n0, int64_t 
 //   POL 0  everything default-cached: the launch's working set fits the 256 MiB Infinity Cache;
 //   POL 1  inputs streamed (nt), outputs written through but kept (sc0 sc1): the next launch reads what this one
 //          wrote and the output alone still fits the Infinity Cache (state ping-pong of 2^22 cubes);
-//   POL 2  inputs streamed, outputs streamed (sc0 sc1 nt): beyond that.
+//   POL 2  inputs streamed, outputs streamed (sc0 sc1 nt): beyond that;
+//   POL 3  state rows default-cached, side outputs streamed: the STATE fits the Infinity Cache but state + code + reward
+//          would not (in-place steps of 2^22 cubes with the fused code, ping-pong of 2^21).
+// SIDE = the outputs nobody re-reads in the next launch (compact code, done, reward): under POL 1 they are streamed past
+// the Infinity Cache so that they do not push the kept state rows out of it (226 MB of state + 84 MB of code would not fit).
+#ifndef RC_SIDE_AUX_POL1
+#define RC_SIDE_AUX_POL1 kAuxStreamStore
+#endif
 template <int POL> struct RowPolicy;
-template <> struct RowPolicy<0> { static constexpr int LD = kAuxCached, ST = kAuxCached; };
-template <> struct RowPolicy<1> { static constexpr int LD = kAuxStreamLoad, ST = kAuxKeepStore; };
-template <> struct RowPolicy<2> { static constexpr int LD = kAuxStreamLoad, ST = kAuxStreamStore; };
+template <> struct RowPolicy<0> { static constexpr int LD = kAuxCached, ST = kAuxCached, SIDE = kAuxCached; };
+template <> struct RowPolicy<1> { static constexpr int LD = kAuxStreamLoad, ST = kAuxKeepStore, SIDE = RC_SIDE_AUX_POL1; };
+template <> struct RowPolicy<2> { static constexpr int LD = kAuxStreamLoad, ST = kAuxStreamStore, SIDE = kAuxStreamStore; };
+template <> struct RowPolicy<3> { static constexpr int LD = kAuxCached, ST = kAuxCached, SIDE = kAuxStreamStore; };
 
 // One lane = 4*V consecutive cubes.  MOVE: apply actions; STORE: write the state rows;
 // CODE: write the compact code rows.  FULL: every pack of the wave lies
@@ -131,8 +140,32 @@ __device__ __forceinline__ void step_body(const StepArgs &a, int64_t g0, uint32_
     }
     if (a.done != nullptr || a.reward != nullptr) {
         const Pk<V> dn = done_bytes(unsolved<T, V>(s));
-        if (a.done) st_tail<V>(a.done, n0, n, dn);
-        if (a.reward) store_reward<V>(a.reward, n0, n, dn);
+        if constexpr (FULL) {                                  // whole packs: buffer stores with the side-output policy
+            if (a.done) bst<V, P::SIDE>(make_srd(a.done + g0), lo, 0, dn);
+            if (a.reward) {
+                // every store instruction writes 1 KiB of CONTIGUOUS floats (streamed partial lines are slow: a lane's own 8 cubes
+                // would put its two 16-byte pieces 32 bytes apart).  V = 2: instruction h covers cubes 256h + 4l .. + 3 of lane l,
+                // whose done bytes sit in dword (l & 1) of lane 32h + l/2 -- one wave shuffle per dword.
+                const __amdgpu_buffer_rsrc_t r = make_srd(a.reward + g0);
+                const int lane = (int)(threadIdx.x & (kWave - 1));
+#pragma unroll
+                for (int h = 0; h < V; ++h) {
+                    uint32_t dd = dn.d[0];
+                    if constexpr (V == 2) {
+                        const int src = 32 * h + (lane >> 1);
+                        const uint32_t d0 = (uint32_t)__shfl((int)dn.d[0], src), d1 = (uint32_t)__shfl((int)dn.d[1], src);
+                        dd = (lane & 1) ? d1 : d0;
+                    }
+                    Pk<4> f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f.d[j] = __float_as_uint(reward_of(dd, j));
+                    bst<4, P::SIDE>(r, (uint32_t)lane * 16u, (uint32_t)h * 1024u, f);
+                }
+            }
+        } else {
+            if (a.done) st_tail<V>(a.done, n0, n, dn);
+            if (a.reward) store_reward<V>(a.reward, n0, n, dn);
+        }
     }
     if constexpr (CODE) {
         Pk<V> c[T::SLOTS];
@@ -140,7 +173,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, int64_t g0, uint32_
         const __amdgpu_buffer_rsrc_t r = make_srd(a.code + tile_off(g0, a.code_pitch, a.sh_code, T::SLOTS));
         const uint32_t rs = (uint32_t)a.code_pitch;
 #pragma unroll
-        for (int p = 0; p < T::SLOTS; ++p) bst<V, P::ST>(r, lo, p * rs, c[p]);
+        for (int p = 0; p < T::SLOTS; ++p) bst<V, P::SIDE>(r, lo, p * rs, c[p]);
     }
 }
 
@@ -324,12 +357,15 @@ __global__ void __launch_bounds__(kWave) k_expand(ExpandArgs a) {
 }
 
 // ------------------------------------------------------------------------------- ADI
+constexpr int kMaxSegs = 16;
 struct AdiArgs {
     uint64_t seed, stream_id;
     int64_t walk_offset, n_walks, pitch, tiles;   // tiles * pitch = padded walk count of one [.] row
     int depth, parts, shift;
     const uint8_t *actions_in;
     uint8_t *actions_out, *parents, *parent_code, *children, *child_code, *child_solved;
+    int segs;                                     // depth segments per walk group (1..kMaxSegs)
+    uint16_t seg_lo[kMaxSegs + 1];                // segment s emits depths [seg_lo[s], seg_lo[s + 1])
 };
 
 // One wave = 256*V walks, kept in registers for all `depth` steps (persistent over depth).
@@ -337,11 +373,18 @@ struct AdiArgs {
 // the children, which is where all the bytes go; part 0 also writes actions and parents.
 // Large batches run V = 2 (8 walks per lane, 512 B per store instruction) with ONE wave per walk group
 // (pick_geometry; DESIGN.md "ADI write path").
+// `segs` waves split the DEPTH range of a walk group: the wave of segment s replays the moves of depths
+// < seg_lo[s] without any output (RNG + move: ~1/5 of a full depth with codes), then emits its own depths.  Code-only
+// generation is VALU-bound with one wave per 256 walks (fewer waves than SIMDs at 100k walks): depth segments fill the chip
+// without duplicating the code look-ups the way `parts` does.
 template <class T, int V, bool CODE>
 __global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
     const int64_t item = blockIdx.x;
-    const int64_t g = item / a.parts;
-    const int part = (int)(item - g * a.parts);
+    const int ps = a.parts * a.segs;
+    const int64_t g = item / ps;
+    const int sub = (int)(item - g * ps);
+    const int seg = sub / a.parts, part = sub - seg * a.parts;
+    const int d_lo = a.seg_lo[seg], d_hi = a.seg_lo[seg + 1];
     const int64_t g0 = g * (kWave * 4 * V);
     const uint32_t lo = threadIdx.x * (4 * V);
     const int64_t w0 = g0 + lo;
@@ -357,7 +400,7 @@ __global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
     const int64_t wp = a.tiles * a.pitch;
     const uint32_t rs = (uint32_t)a.pitch;
     const int64_t st_off = tile_off(g0, a.pitch, a.shift, T::S), code_off = tile_off(g0, a.pitch, a.shift, T::SLOTS);
-    for (int d = 0; d < a.depth; ++d) {
+    for (int d = 0; d < d_hi; ++d) {
         Pk<V> act;
         if (a.actions_in != nullptr) {
             act = bld<V, kAuxCached>(make_srd(a.actions_in + (int64_t)d * wp + g0), lo, 0);
@@ -379,6 +422,7 @@ __global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
 #pragma unroll
             for (int i = 0; i < T::S; ++i) s[i] = o[i];
         }
+        if (d < d_lo) continue;                               // another segment's depth: replayed, nothing emitted (wave-uniform)
         FamilyCodes<T, V> fam;
         ChildFlags<T, V> cf;
         if constexpr (CODE) family_codes<T, V>(s, fam);
@@ -737,13 +781,14 @@ int fail(int code, const char *fmt, const char *detail = "") {
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline bool bad_pitch(int64_t pitch, int64_t n) { return pitch < n || (pitch & 15) != 0; }  // single-tile buffers
 // state / code buffers may be tiled: one tile (pitch >= n, pitch % 16 == 0) or several
-// (pitch a power of two >= 1024).  Returns the shift for tile_off, or -1 if the pitch is bad.
+// (pitch a power of two >= kMinTile = 512, the widest wave span).  Returns the shift for tile_off, or -1 if the pitch is bad.
 // Row offsets inside a tile are 32-bit scalar offsets of buffer instructions: rows * pitch < 2^32
 // (a single tile of more than 79 M 3x3x3 cubes has to be split into tiles).
+constexpr int64_t kMinTile = 512;
 inline int tile_shift(int64_t pitch, int64_t n, int rows = 54) {
     if (pitch <= 0 || (pitch & 15) != 0 || pitch * rows >= ((int64_t)1 << 32)) return -1;
     if (n <= pitch) return 63;
-    if (pitch < 1024 || (pitch & (pitch - 1)) != 0) return -1;
+    if (pitch < kMinTile || (pitch & (pitch - 1)) != 0) return -1;
     int sh = 0;
     while (((int64_t)1 << sh) < pitch) ++sh;
     return sh;
@@ -752,6 +797,18 @@ inline hipStream_t S(void *s) { return static_cast<hipStream_t>(s); }
 inline bool grid_ok(int64_t blocks) { return blocks > 0 && blocks <= 0x7fffffff; }
 #define RC_GRID(blocks) \
     do { if (!grid_ok(blocks)) return fail(RC_EINVAL, "too many cubes for one launch%s"); } while (0)
+
+// rc_init bookkeeping: every launching entry point returns RC_ENODEV until rc_init(device) has succeeded for the CURRENT device
+// (a plain-C caller that skips it would otherwise see a raw HIP launch error, or run on a device that is not gfx950).
+std::atomic<uint64_t> g_inited[4];   // one bit per device ordinal (256 devices)
+int need_init() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(RC_ENODEV, "no current HIP device%s");
+    if (dev < 0 || dev >= 256 || !((g_inited[dev >> 6].load(std::memory_order_acquire) >> (dev & 63)) & 1))
+        return fail(RC_ENODEV, "rc_init was not called for the current device%s");
+    return RC_OK;
+}
+#define RC_NEED_INIT() do { if (int rc_ = need_init()) return rc_; } while (0)
 
 template <class F>
 int by_size(int cube_size, F &&f) {
@@ -768,33 +825,47 @@ int by_size(int cube_size, F &&f) {
 // Measured on MI355X at 4M cubes (tools/exp/exp_step.hip, exp_step2.hip): V = 2 (8 cubes per lane, dwordx2 rows)
 // beats V = 1; V = 4 (16 cubes per lane, 345 VGPRs) never beat V = 2 and is no longer instantiated.  The row-traffic
 // policy follows the working set (RowPolicy).
+// Round-3 sweep over 2^18 .. 2^24 cubes x {done, reward, code, in place} (profiles/r03_ab.json): with every side store a
+// contiguous 1-KiB instruction V = 2 wins or ties everywhere from 2^18 cubes up (V = 1 is 2 % ahead only around 2^21).
 int pick_v(int64_t n, int variant) {
     const int v = variant % 10;
     if (v == 1 || v == 2) return v;
     return n >= (int64_t)1 << 18 ? 2 : 1;
 }
 constexpr int64_t kMallBytes = (int64_t)240 << 20;   // what we count on of the 256 MiB Infinity Cache
-int pick_policy(int64_t in_bytes, int64_t out_bytes, bool in_place, int variant) {
+int pick_policy(int64_t in_bytes, int64_t out_bytes, bool in_place, int64_t side_bytes, int variant) {
     const int p = (variant / 10) % 10;
     if (p == 1) return 2;
     if (p == 2) return 0;
     if (p == 3) return 1;
+    if (p == 4) return 3;
     const int64_t touched = in_place ? in_bytes : in_bytes + out_bytes;
-    if (touched <= kMallBytes) return 0;               // resident: default-cached (1M cubes run out of the Infinity Cache)
+    if (touched + side_bytes <= kMallBytes) return 0;   // resident: default-cached (1M cubes run out of the Infinity Cache)
+    if (touched <= kMallBytes) return 3;                // the state is resident, its side outputs (code, reward, done) stream past it
     if (!in_place && out_bytes > 0 && out_bytes <= kMallBytes) return 1;   // stream the input, keep the output for the next launch
     return 2;
 }
+// bytes of the outputs no later launch of the env loop reads back: compact code, done flags, reward
+template <class T>
+int64_t side_bytes(int64_t n, bool code, bool done, bool reward) { return n * ((code ? T::SLOTS : 0) + (done ? 1 : 0) + (reward ? 4 : 0)); }
+
+struct StepPlan { int v, pol; };
+// One place decides pack width and row-traffic policy of a step launch (the launcher and rc_describe_dispatch both call it).
+template <class T>
+StepPlan plan_step(int64_t n, bool writes, bool in_place, bool code, bool done, bool reward, int variant) {
+    const int pol = pick_policy(n * T::S, writes ? n * T::S : 0, writes && in_place, side_bytes<T>(n, code, done, reward), variant);
+    return {pick_v(n, variant), pol};
+}
 
 template <class T, int V, bool MOVE, bool STORE, bool CODE>
-int launch_step(const StepArgs &a, hipStream_t st, int variant) {
+int launch_step(const StepArgs &a, hipStream_t st, int pol) {
     constexpr int BLOCK = 64;
     const int64_t lanes = (a.n + 4 * V - 1) / (4 * V);
     const int64_t blocks = (lanes + BLOCK - 1) / BLOCK;
     RC_GRID(blocks);
-    const bool writes = STORE && a.out != nullptr;
-    const int pol = pick_policy(a.n * T::S, writes ? a.n * T::S : 0, writes && a.out == a.in, variant);
     const dim3 g((unsigned)blocks), b(BLOCK);
-    if (pol == 2) hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, 2, BLOCK>), g, b, 0, st, a);
+    if (pol == 3) hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, 3, BLOCK>), g, b, 0, st, a);
+    else if (pol == 2) hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, 2, BLOCK>), g, b, 0, st, a);
     else if (pol == 1) hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, 1, BLOCK>), g, b, 0, st, a);
     else hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, 0, BLOCK>), g, b, 0, st, a);
     RC_HIP(hipGetLastError());
@@ -803,7 +874,9 @@ int launch_step(const StepArgs &a, hipStream_t st, int variant) {
 
 template <class T, bool MOVE, bool STORE, bool CODE>
 int dispatch_step(const StepArgs &a, hipStream_t st, int variant) {
-    return pick_v(a.n, variant) == 2 ? launch_step<T, 2, MOVE, STORE, CODE>(a, st, variant) : launch_step<T, 1, MOVE, STORE, CODE>(a, st, variant);
+    const bool writes = STORE && a.out != nullptr;
+    const StepPlan p = plan_step<T>(a.n, writes, writes && a.out == a.in, CODE, a.done != nullptr, a.reward != nullptr, variant);
+    return p.v == 2 ? launch_step<T, 2, MOVE, STORE, CODE>(a, st, p.pol) : launch_step<T, 1, MOVE, STORE, CODE>(a, st, p.pol);
 }
 
 // Measured at 1M cubes (tools/microbench.py densetile): 256-cube tiles 5.4 TB/s (f32) / 6.3 TB/s (u8) against
@@ -860,7 +933,7 @@ int check_fmt(void *onehot, int fmt, int64_t code_pitch, int64_t n, int *sh_code
     if ((fmt == RC_FMT_NONE) != (onehot == nullptr)) return fail(RC_EINVAL, "onehot pointer and fmt disagree%s");
     if (onehot && !aligned16(onehot)) return fail(RC_EINVAL, "onehot must be 16-byte aligned%s");
     *sh_code = 63;
-    if (fmt == RC_FMT_CODE && (*sh_code = tile_shift(code_pitch, n, 20)) < 0) return fail(RC_EINVAL, "code_pitch: need pitch %% 16 == 0 and pitch >= n_cubes, or a power-of-two tile >= 1024%s");
+    if (fmt == RC_FMT_CODE && (*sh_code = tile_shift(code_pitch, n, 20)) < 0) return fail(RC_EINVAL, "code_pitch: need pitch %% 16 == 0 and pitch >= n_cubes, or a power-of-two tile >= 512%s");
     return RC_OK;
 }
 
@@ -869,8 +942,9 @@ int check_fmt(void *onehot, int fmt, int64_t code_pitch, int64_t n, int *sh_code
 // against 0.41-0.43 ms with 2346 waves of 4 walks per lane; 16 walks per lane would be better still for the stores alone
 // (7.2 TB/s in the store-only harness) but one wave per 1024 walks cannot hide the walk's VALU work (0.44 ms).  Small
 // batches are latency-bound instead: spread them over the chip.  Code-only expansion is VALU-bound: narrow packs.
-struct Geometry { int v, parts; };
-Geometry pick_geometry(int64_t n, int A, int variant, bool stickers_out, int64_t out_bytes) {
+struct Geometry { int v, parts, segs; };
+constexpr double kReplayCostCodes = 0.2, kReplayCostStickers = 0.35;   // replayed depth / emitted depth (RNG + move against everything)
+Geometry pick_geometry(int64_t n, int A, int variant, bool stickers_out, int64_t out_bytes, bool codes = false) {
     const int fv = variant % 10, fp = (variant / 1000) % 100;
     const bool stream = stickers_out && out_bytes >= ((int64_t)256 << 20);
     const int64_t want = stream ? 96 : stickers_out ? 2048 : 700;
@@ -882,7 +956,51 @@ Geometry pick_geometry(int64_t n, int A, int variant, bool stickers_out, int64_t
     if (fp >= 1 && fp <= A) parts = fp;
     else while (parts < A && groups * parts < want) ++parts;
     while (A % parts) ++parts;
-    return {v, parts};
+    return {v, parts, 1};
+}
+// Code-only ADI (no child stickers): one wave per walk group leaves most SIMDs idle or alone with a long serial chain, and
+// `parts` duplicates the code look-ups.  DEPTH SEGMENTS split the work without duplicating them; measured at 100k walks x 30
+// (three repeats, profiles/r03_ab.json): 8 walks per lane x 3 segments (588 waves) 148-149 us every time, 4 walks per lane x
+// 2 segments (782 waves) 146-160 us, round 2's 4 walks per lane x 2 parts 162-166 us; more segments lose to the replayed
+// moves.  Rule: about 600 waves; wide packs once that still leaves >= 2 segments' worth of groups.
+Geometry pick_geometry_adi(int64_t n, int A, int variant, bool stickers_out, int64_t out_bytes, bool codes) {
+    Geometry g = pick_geometry(n, A, variant, stickers_out, out_bytes, codes);
+    if (codes && !stickers_out) {
+        const int fv = variant % 10, fp = (variant / 1000) % 100;
+        g.v = fv == 1 || fv == 2 ? fv : (n >= 64 * kWave * 8 ? 2 : 1);
+        g.parts = fp >= 1 && fp <= A ? g.parts : 1;
+        const int64_t waves = (n + kWave * 4 * g.v - 1) / (kWave * 4 * g.v) * g.parts;
+        const int64_t segs = (600 + waves / 2) / (waves > 0 ? waves : 1);
+        g.segs = segs < 1 ? 1 : segs > kMaxSegs ? kMaxSegs : (int)segs;
+    }
+    return g;
+}
+
+// Depth segments of the ADI kernel (k_adi): boundaries that equalise the work of the segments when a replayed depth
+// costs `replay` of an emitted one (segment s replays seg_lo[s] depths and emits seg_lo[s+1] - seg_lo[s]).
+void fill_segments(AdiArgs &a, int segs, double replay) {
+    if (segs > a.depth) segs = a.depth;
+    if (segs > kMaxSegs) segs = kMaxSegs;
+    if (segs < 1) segs = 1;
+    a.segs = segs;
+    double lo_c = 0, hi_c = a.depth;                        // bisection on the per-segment cost
+    for (int it = 0; it < 60; ++it) {
+        const double c = 0.5 * (lo_c + hi_c);
+        double lo = 0;
+        for (int k = 0; k < segs; ++k) lo += c - replay * lo > 0 ? c - replay * lo : 0;
+        (lo < a.depth ? lo_c : hi_c) = c;
+    }
+    double lo = 0;
+    int prev = 0;
+    a.seg_lo[0] = 0;
+    for (int k = 1; k <= segs; ++k) {
+        lo += hi_c - replay * lo;
+        int b = k == segs ? a.depth : (int)(lo + 0.5);
+        if (b < prev + 1) b = prev + 1;                      // every segment emits at least one depth ...
+        if (b > a.depth - (segs - k)) b = a.depth - (segs - k);   // ... and leaves one for each later segment
+        a.seg_lo[k] = (uint16_t)b;
+        prev = b;
+    }
 }
 
 template <class T, int V>
@@ -899,8 +1017,8 @@ int launch_expand(ExpandArgs a, hipStream_t st) {
 template <class T, int V>
 int launch_adi(AdiArgs a, hipStream_t st) {
     const int64_t groups = (a.n_walks + kWave * 4 * V - 1) / (kWave * 4 * V);
-    RC_GRID(groups * a.parts);
-    const dim3 g((unsigned)(groups * a.parts)), b(kWave);
+    RC_GRID(groups * a.parts * a.segs);
+    const dim3 g((unsigned)(groups * a.parts * a.segs)), b(kWave);
     if (a.parent_code || a.child_code) hipLaunchKernelGGL((k_adi<T, V, true>), g, b, 0, st, a);
     else hipLaunchKernelGGL((k_adi<T, V, false>), g, b, 0, st, a);
     RC_HIP(hipGetLastError());
@@ -912,7 +1030,7 @@ int launch_adi(AdiArgs a, hipStream_t st) {
 // =============================================================================== C ABI
 extern "C" {
 
-int rc_version(void) { return 200; }
+int rc_version(void) { return 300; }
 
 const char *rc_last_error(void) { return t_err; }
 
@@ -930,6 +1048,7 @@ int rc_init(int device) {
     const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_status), &zero, sizeof zero);
     RC_HIP(hipSetDevice(prev));
     RC_HIP(e);
+    if (device < 256) g_inited[device >> 6].fetch_or((uint64_t)1 << (device & 63), std::memory_order_release);
     return RC_OK;
 }
 
@@ -949,12 +1068,13 @@ int rc_get_tables(int cube_size, uint8_t *perm, uint8_t *solved, uint8_t *corner
 }
 
 int rc_fill_solved(uint8_t *stp, int64_t n, int64_t pitch, int cube_size, void *stream) {
+    RC_NEED_INIT();
     const int sh = tile_shift(pitch, n);
     if (!stp || !aligned16(stp) || n < 0 || sh < 0) return fail(RC_EINVAL, "rc_fill_solved: bad buffer / pitch%s");
     if (n == 0) return RC_OK;
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
-        const int64_t blocks = (n + kWave * 16 - 1) / (kWave * 16);
+        const int64_t blocks = (n + kWave * 8 - 1) / (kWave * 8);
         RC_GRID(blocks);
         hipLaunchKernelGGL((k_fill_solved<T>), dim3((unsigned)blocks), dim3(kWave), 0, S(stream), stp, n, pitch, sh);
         RC_HIP(hipGetLastError());
@@ -965,6 +1085,7 @@ int rc_fill_solved(uint8_t *stp, int64_t n, int64_t pitch, int cube_size, void *
 static int step_common(const uint8_t *in, uint8_t *out, const uint8_t *actions, int64_t n, int64_t pitch_in, int64_t pitch_out,
                        int cube_size, float *reward, uint8_t *done, void *onehot, int fmt, int64_t code_pitch, void *stream,
                        bool move, bool store, int variant) {
+    RC_NEED_INIT();
     const int sh_in = tile_shift(pitch_in, n), sh_out = store ? tile_shift(pitch_out, n) : 63;
     int sh_code = 63;
     if (!in || !aligned16(in) || n < 0 || sh_in < 0) return fail(RC_EINVAL, "bad input state buffer / pitch%s");
@@ -1004,6 +1125,7 @@ int rc_apply_moves(const uint8_t *in, uint8_t *out, const uint8_t *actions, int6
 int rc_scramble(uint8_t *stp, int64_t n, int64_t pitch, int cube_size, int depth, uint64_t seed, uint64_t stream_id,
                 int64_t walk_offset, const uint8_t *actions_in, uint8_t *actions_out, int64_t act_pitch, uint8_t *done,
                 float *reward, void *stream) {
+    RC_NEED_INIT();
     const int sh = tile_shift(pitch, n);
     if (!stp || !aligned16(stp) || n < 0 || depth < 0 || sh < 0) return fail(RC_EINVAL, "rc_scramble: bad state buffer / pitch%s");
     if ((actions_in || actions_out) && bad_pitch(act_pitch, n)) return fail(RC_EINVAL, "rc_scramble: bad act_pitch%s");
@@ -1023,6 +1145,7 @@ int rc_scramble(uint8_t *stp, int64_t n, int64_t pitch, int cube_size, int depth
 
 int rc_legacy_scramble_actions(const uint32_t *seeds, const int32_t *counts, int count_uniform, int kmax, int64_t n, int cube_size,
                                 uint8_t *actions_out, int64_t pitch, void *stream) {
+    RC_NEED_INIT();
     if (!seeds || !actions_out || n < 0 || kmax < 0 || bad_pitch(pitch, n)) return fail(RC_EINVAL, "rc_legacy_scramble_actions: bad arguments%s");
     if (!counts && (count_uniform < 0 || count_uniform > kmax)) return fail(RC_EINVAL, "rc_legacy_scramble_actions: count_uniform must be in 0..kmax%s");
     if (n == 0 || kmax == 0) return RC_OK;
@@ -1047,6 +1170,7 @@ int rc_encode(const uint8_t *stp, int64_t n, int64_t pitch, int cube_size, void 
 }
 
 int rc_onehot_from_code(const uint8_t *code, int64_t n, int64_t code_pitch, int cube_size, void *onehot, int fmt, void *stream) {
+    RC_NEED_INIT();
     const int sh = tile_shift(code_pitch, n, 20);
     if (!code || !aligned16(code) || n < 0 || sh < 0) return fail(RC_EINVAL, "bad code buffer / pitch%s");
     if (fmt < RC_FMT_U8 || fmt > RC_FMT_BF16 || !onehot || !aligned16(onehot)) return fail(RC_EINVAL, "rc_onehot_from_code: dense fmt and aligned buffer required%s");
@@ -1062,6 +1186,7 @@ int rc_onehot_from_code(const uint8_t *code, int64_t n, int64_t code_pitch, int 
 
 int rc_expand_children_ex(const uint8_t *in, int64_t n, int64_t pitch_in, int cube_size, uint8_t *children, uint8_t *child_solved,
                           uint8_t *child_code, int64_t pitch_out, void *stream, int variant) {
+    RC_NEED_INIT();
     const int sh_in = tile_shift(pitch_in, n), sh_out = tile_shift(pitch_out, n);
     if (!in || !aligned16(in) || n < 0 || sh_in < 0 || sh_out < 0) return fail(RC_EINVAL, "rc_expand_children: bad buffer / pitch%s");
     if (!children && !child_solved && !child_code) return fail(RC_EINVAL, "rc_expand_children: nothing to write%s");
@@ -1070,7 +1195,7 @@ int rc_expand_children_ex(const uint8_t *in, int64_t n, int64_t pitch_in, int cu
     if (n == 0) return RC_OK;
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
-        const Geometry geo = pick_geometry(n, T::A, variant, children != nullptr, n * T::S * T::A);
+        const Geometry geo = pick_geometry(n, T::A, variant, children != nullptr, n * T::S * T::A, child_code != nullptr);
         ExpandArgs a{in, n, pitch_in, children, child_solved, child_code, pitch_out, n <= pitch_out ? 1 : (n + pitch_out - 1) / pitch_out,
                      geo.parts, sh_in, sh_out};
         hipStream_t st = S(stream);
@@ -1086,6 +1211,7 @@ int rc_expand_children(const uint8_t *in, int64_t n, int64_t pitch_in, int cube_
 int rc_adi_generate_ex(uint64_t seed, uint64_t stream_id, int64_t walk_offset, int64_t n_walks, int depth, int cube_size, int64_t pitch,
                        const uint8_t *actions_in, uint8_t *actions_out, uint8_t *parents, uint8_t *parent_code, uint8_t *children,
                        uint8_t *child_code, uint8_t *child_solved, void *stream, int variant) {
+    RC_NEED_INIT();
     const int sh = tile_shift(pitch, n_walks);
     if (n_walks < 0 || depth < 0 || sh < 0) return fail(RC_EINVAL, "rc_adi_generate: bad sizes / pitch%s");
     const void *ptrs[] = {actions_in, actions_out, parents, parent_code, children, child_code, child_solved};
@@ -1095,10 +1221,15 @@ int rc_adi_generate_ex(uint64_t seed, uint64_t stream_id, int64_t walk_offset, i
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
         const bool any_child = children || child_code || child_solved;
-        Geometry geo = pick_geometry(n_walks, T::A, variant, children != nullptr, n_walks * depth * T::S * T::A);
+        Geometry geo = pick_geometry_adi(n_walks, T::A, variant, children != nullptr, n_walks * depth * T::S * T::A, parent_code || child_code);
         if (!any_child && (variant / 1000) % 100 == 0) geo.parts = 1;
         AdiArgs a{seed, stream_id, walk_offset, n_walks, pitch, n_walks <= pitch ? 1 : (n_walks + pitch - 1) / pitch, depth,
-                  geo.parts, sh, actions_in, actions_out, parents, parent_code, children, child_code, child_solved};
+                  geo.parts, sh, actions_in, actions_out, parents, parent_code, children, child_code, child_solved, 1, {}};
+        if (depth > 0xffff) return fail(RC_EINVAL, "rc_adi_generate: depth must be below 65536%s");
+        const int fsegs = (variant / 1000000) % 100;
+        const bool codes = parent_code || child_code;
+        // a replayed depth is RNG + move; an emitted one adds the flags, the code look-ups and the stores
+        fill_segments(a, fsegs ? fsegs : geo.segs, codes ? kReplayCostCodes : kReplayCostStickers);
         hipStream_t st = S(stream);
         return geo.v == 2 ? launch_adi<T, 2>(a, st) : launch_adi<T, 1>(a, st);
     });
@@ -1113,6 +1244,7 @@ int rc_adi_generate(uint64_t seed, uint64_t stream_id, int64_t walk_offset, int6
 
 int rc_adi_targets(const float *child_value, const uint8_t *child_solved, const float *parent_value, const double *weight, int64_t n,
                    int64_t pitch, int cube_size, float *target_value, int32_t *target_policy, double *error, void *stream) {
+    RC_NEED_INIT();
     if (!child_value || !child_solved || !target_value || !target_policy || n < 0 || pitch < n) return fail(RC_EINVAL, "rc_adi_targets: bad arguments%s");
     if (error && (!parent_value || !weight)) return fail(RC_EINVAL, "rc_adi_targets: error needs parent_value and weight%s");
     if (n == 0) return RC_OK;
@@ -1128,25 +1260,32 @@ int rc_adi_targets(const float *child_value, const uint8_t *child_solved, const 
 
 static int facade_wait(uint8_t *host_out, uint32_t seq, void *stream, const char *who);
 
-// host_out is dereferenced by the HOST while polling: it must be host (pinned) memory.  Checked once per buffer and thread.
-static int facade_check_host(const uint8_t *host_out, const char *who) {
-    static thread_local const uint8_t *checked = nullptr;
-    if (host_out == checked) return RC_OK;
+// host_out is dereferenced by the HOST while polling and written by the KERNEL through its device alias: for hipHostMalloc'ed
+// memory the two addresses are equal, for hipHostRegister'ed memory (e.g. torch with pinned_use_cuda_host_register) they may
+// differ, so the kernel always gets attr.devicePointer.  The (host, device) pair of the last buffer is cached per thread;
+// rc_facade_release drops it (call it before freeing a buffer whose address may be reused by non-pinned memory).
+struct FacadeAlias { const uint8_t *host; uint8_t *dev; };
+static thread_local FacadeAlias t_alias{nullptr, nullptr};
+static int facade_check_host(const uint8_t *host_out, const char *who, uint8_t **dev_alias) {
+    if (host_out == t_alias.host) { *dev_alias = t_alias.dev; return RC_OK; }
     hipPointerAttribute_t attr;
-    if (hipPointerGetAttributes(&attr, host_out) != hipSuccess || attr.type != hipMemoryTypeHost) {
+    if (hipPointerGetAttributes(&attr, host_out) != hipSuccess || attr.type != hipMemoryTypeHost || attr.devicePointer == nullptr) {
         (void)hipGetLastError();
         return fail(RC_EINVAL, "%s: host_out must be host-mapped pinned memory (hipHostMalloc / torch pin_memory)", who);
     }
-    checked = host_out;
+    t_alias = {host_out, static_cast<uint8_t *>(attr.devicePointer)};
+    *dev_alias = t_alias.dev;
     return RC_OK;
 }
 
 int rc_facade_steps(uint8_t *stp, int64_t pitch, int cube_size, const uint8_t *actions, int n_actions, uint8_t *host_out, uint32_t seq,
                     int wait, void *stream) {
+    RC_NEED_INIT();
     if (!stp || !host_out || pitch <= 0 || pitch * 54 >= ((int64_t)1 << 32)) return fail(RC_EINVAL, "rc_facade_steps: bad arguments%s");
     if (n_actions < 0 || (n_actions > 0 && !actions)) return fail(RC_EINVAL, "rc_facade_steps: bad action list%s");
     if (seq == 0) return fail(RC_EINVAL, "rc_facade_steps: seq must be non-zero%s");
-    if (int rc = facade_check_host(host_out, "rc_facade_steps")) return rc;
+    uint8_t *dev_out = nullptr;
+    if (int rc = facade_check_host(host_out, "rc_facade_steps", &dev_out)) return rc;
     const int rc = by_size(cube_size, [&](auto t) {
         using T = decltype(t);
         int done = 0;
@@ -1156,7 +1295,7 @@ int rc_facade_steps(uint8_t *stp, int64_t pitch, int cube_size, const uint8_t *a
             fa.n = (uint32_t)m;
             memcpy(fa.a, actions + done, (size_t)m);
             done += m;
-            hipLaunchKernelGGL((k_facade_step<T>), dim3(1), dim3(kWave), 0, S(stream), stp, (uint32_t)pitch, fa, host_out, done == n_actions ? seq : 0u);
+            hipLaunchKernelGGL((k_facade_step<T>), dim3(1), dim3(kWave), 0, S(stream), stp, (uint32_t)pitch, fa, dev_out, done == n_actions ? seq : 0u);
             RC_HIP(hipGetLastError());
         } while (done < n_actions);
         return RC_OK;
@@ -1184,13 +1323,20 @@ static int facade_wait(uint8_t *host_out, uint32_t seq, void *stream, const char
     return fail(RC_EHIP, "%s: the result never reached host_out (is it host-mapped pinned memory?)", who);
 }
 
+int rc_facade_release(const uint8_t *host_out) {
+    if (host_out == nullptr || host_out == t_alias.host) t_alias = {nullptr, nullptr};
+    return RC_OK;
+}
+
 int rc_facade_expand(const uint8_t *stp, int64_t pitch, int cube_size, uint8_t *host_out, uint32_t seq, int dense, int wait, void *stream) {
+    RC_NEED_INIT();
     if (!stp || !host_out || pitch <= 0 || pitch * 54 >= ((int64_t)1 << 32)) return fail(RC_EINVAL, "rc_facade_expand: bad arguments%s");
     if (seq == 0) return fail(RC_EINVAL, "rc_facade_expand: seq must be non-zero%s");
-    if (int rc = facade_check_host(host_out, "rc_facade_expand")) return rc;
+    uint8_t *dev_out = nullptr;
+    if (int rc = facade_check_host(host_out, "rc_facade_expand", &dev_out)) return rc;
     const int rc = by_size(cube_size, [&](auto t) {
         using T = decltype(t);
-        hipLaunchKernelGGL((k_facade_expand<T>), dim3(1), dim3(kWave), 0, S(stream), stp, (uint32_t)pitch, host_out, seq, dense);
+        hipLaunchKernelGGL((k_facade_expand<T>), dim3(1), dim3(kWave), 0, S(stream), stp, (uint32_t)pitch, dev_out, seq, dense);
         RC_HIP(hipGetLastError());
         return RC_OK;
     });
@@ -1198,7 +1344,61 @@ int rc_facade_expand(const uint8_t *stp, int64_t pitch, int cube_size, uint8_t *
     return facade_wait(host_out, seq, stream, "rc_facade_expand");
 }
 
+// What a call WOULD launch, from the same pick_* functions the launchers use (benchmarks label their records with this, so a
+// change of the dispatch policy cannot leave a stale kernel name behind).
+int rc_describe_dispatch(int op, int cube_size, int64_t n, int depth, unsigned outputs, int fmt, int variant, char *buf, int buflen) {
+    if (!buf || buflen < 16) return fail(RC_EINVAL, "rc_describe_dispatch: buffer too small%s");
+    if (n <= 0) return fail(RC_EINVAL, "rc_describe_dispatch: n must be positive%s");
+    return by_size(cube_size, [&](auto t) {
+        using T = decltype(t);
+        const char *cube = T::SIZE == 3 ? "Cube3" : "Cube2";
+        const bool states = outputs & RC_OUT_STATES, code = outputs & RC_OUT_CODE;
+        if (op == RC_OP_STEP) {
+            if (fmt >= RC_FMT_U8 && fmt <= RC_FMT_BF16) {
+                static const char *const names[] = {"", "", "u8", "f16", "f32", "bf16"};
+                const int tile = dense_tile(n, variant);
+                snprintf(buf, buflen, "k_step_dense<%s,%s,%s,TILE=%d> grid=%lld block=%d", cube, names[fmt], states ? "move,store" : "encode",
+                         tile, (long long)dense_grid((n + tile - 1) / tile, fmt), kDenseBlock);
+                return RC_OK;
+            }
+            const bool with_code = code || fmt == RC_FMT_CODE;
+            const StepPlan p = plan_step<T>(n, states, states && (outputs & RC_OUT_INPLACE), with_code, outputs & RC_OUT_DONE, outputs & RC_OUT_REWARD, variant);
+            snprintf(buf, buflen, "k_step<%s,V=%d%s%s,POL=%d> grid=%lld block=64", cube, p.v, states ? ",move,store" : "", with_code ? ",code" : "", p.pol,
+                     (long long)((n + 256 * p.v - 1) / (256 * p.v)));
+            return RC_OK;
+        }
+        if (op == RC_OP_CODE_TO_DENSE) {
+            static const char *const names[] = {"", "", "u8", "f16", "f32", "bf16"};
+            if (fmt < RC_FMT_U8 || fmt > RC_FMT_BF16) return fail(RC_EINVAL, "rc_describe_dispatch: dense fmt required%s");
+            const int tile = dense_tile(n, 0);
+            snprintf(buf, buflen, "k_code_to_dense<%s,%s,TILE=%d> grid=%lld block=%d", cube, names[fmt], tile, (long long)dense_grid((n + tile - 1) / tile, fmt), kDenseBlock);
+            return RC_OK;
+        }
+        if (op == RC_OP_EXPAND) {
+            const Geometry geo = pick_geometry(n, T::A, variant, states, n * T::S * T::A, code);
+            snprintf(buf, buflen, "k_expand<%s,V=%d%s> parts=%d grid=%lld block=64", cube, geo.v, code ? ",code" : "", geo.parts,
+                     (long long)((n + 256 * geo.v - 1) / (256 * geo.v) * geo.parts));
+            return RC_OK;
+        }
+        if (op == RC_OP_ADI) {
+            if (depth <= 0) return fail(RC_EINVAL, "rc_describe_dispatch: depth must be positive%s");
+            Geometry geo = pick_geometry_adi(n, T::A, variant, states, n * depth * T::S * T::A, code);
+            const bool any_child = states || code || (outputs & RC_OUT_FLAGS);
+            if (!any_child && (variant / 1000) % 100 == 0) geo.parts = 1;
+            AdiArgs a{};
+            a.depth = depth;
+            const int fsegs = (variant / 1000000) % 100;
+            fill_segments(a, fsegs ? fsegs : geo.segs, code ? kReplayCostCodes : kReplayCostStickers);
+            snprintf(buf, buflen, "k_adi<%s,V=%d%s> parts=%d segs=%d grid=%lld block=64", cube, geo.v, code ? ",code" : "", geo.parts, a.segs,
+                     (long long)((n + 256 * geo.v - 1) / (256 * geo.v) * geo.parts * a.segs));
+            return RC_OK;
+        }
+        return fail(RC_EINVAL, "rc_describe_dispatch: unknown op%s");
+    });
+}
+
 int rc_read_status(uint32_t *status, void *stream) {
+    RC_NEED_INIT();
     if (!status) return fail(RC_EINVAL, "status is NULL%s");
     // one atomic read-and-clear on the device (bits set by kernels still running on OTHER streams are neither lost nor
     // reported early: they show in a later read); the word travels through a pinned, host-mapped scratch word

@@ -215,7 +215,8 @@ class CubeEnv:
     def get_random_samples(self, replay_buffer, model, sample_scramble_count, sample_cube_count, temperature):
         """ADI samples into replay_buffer (cube_env.py:177-194): for each of sample_cube_count cubes the
         moves come from np.random.randint(action_dim, size=sample_scramble_count) on the global legacy
-        RNG, exactly as the reference draws them; walks, expansion, one-hots and targets run on the GPU."""
+        RNG, exactly as the reference draws them; walks, expansion, one-hots and targets run on the GPU.  A sink with
+        `append_batch` (replay.TensorReplayBuffer) receives the batch as tensors; anything else gets the reference's dicts."""
         from .adi import adi_samples, samples_to_dicts
 
         if sample_cube_count <= 0:
@@ -223,10 +224,14 @@ class CubeEnv:
         actions = np.stack([np.random.randint(self.action_dim, size=sample_scramble_count)
                             for _ in range(sample_cube_count)]).astype(np.uint8)
         if sample_scramble_count > 0:
+            tensor_sink = hasattr(replay_buffer, "append_batch")         # replay.TensorReplayBuffer: no per-sample dicts
             res = adi_samples(model, self.cube_size, sample_cube_count, sample_scramble_count, temperature,
-                              device=self._vec.device, model_device=self.device, actions=actions, want_state_dense=True)
-            for sample in samples_to_dicts(res, self.cube_size):
-                replay_buffer.append(sample)
+                              device=self._vec.device, model_device=self.device, actions=actions, want_state_dense=not tensor_sink)
+            if tensor_sink:
+                replay_buffer.append_batch(res)
+            else:                                                         # the reference's own ReplayBuffer / any list-like sink
+                for sample in samples_to_dicts(res, self.cube_size):
+                    replay_buffer.append(sample)
             # the env is left on the last walk's final state, as in the reference
             self._vec.reset(actions=actions[-1:], scramble_count=sample_scramble_count)
         else:

@@ -6,7 +6,7 @@ validates its tensors and forwards raw pointers + the current HIP stream to libr
 State layout (include/rubikhip.h "State layout"): uint8 tensor [tiles, S, pitch] -- structure of
 arrays in tiles: one row per sticker, one column per cube, `pitch` cubes per tile; cube n sits in
 tile n // pitch, column n % pitch.  A 2-D [S, pitch] tensor is the one-tile case.  Buffers with
-several tiles need a power-of-two pitch >= 1024 (DEFAULT_TILE = 32768 measured best on MI355X).
+several tiles need a power-of-two pitch >= MIN_TILE = 512 (DEFAULT_TILE = 32768 measured best on MI355X).
 Compact code buffers [tiles, SLOTS, pitch] follow the same rule.  Expansion / ADI outputs are
 one-tile ("plain") buffers.
 """
@@ -29,6 +29,7 @@ def _size(cube_size):
 
 
 DEFAULT_TILE = 32768
+MIN_TILE = 512        # the widest wave span (8 cubes per lane): a wave never straddles tiles
 
 
 def _rows(t, rows, n, what):
@@ -51,8 +52,8 @@ def _tiled(t, rows, n, what):
     tiles, _, pitch = t.shape
     if pitch % 16 or tiles * pitch < n:
         raise RubikHipError(f"{what}: pitch {pitch} x {tiles} tiles cannot hold {n} cubes (pitch % 16 must be 0)")
-    if n > pitch and (pitch < 1024 or pitch & (pitch - 1)):
-        raise RubikHipError(f"{what}: a buffer with several tiles needs a power-of-two pitch >= 1024, got {pitch}")
+    if n > pitch and (pitch < MIN_TILE or pitch & (pitch - 1)):
+        raise RubikHipError(f"{what}: a buffer with several tiles needs a power-of-two pitch >= {MIN_TILE}, got {pitch}")
     return pitch
 
 
@@ -214,8 +215,8 @@ def _tiles_of(n, pitch):
         raise RubikHipError(f"pitch {pitch} must be a multiple of 16")
     if n <= pitch:
         return 1
-    if pitch < 1024 or pitch & (pitch - 1):
-        raise RubikHipError(f"{n} cubes in tiles of {pitch}: several tiles need a power-of-two pitch >= 1024")
+    if pitch < MIN_TILE or pitch & (pitch - 1):
+        raise RubikHipError(f"{n} cubes in tiles of {pitch}: several tiles need a power-of-two pitch >= {MIN_TILE}")
     return -(-n // pitch)
 
 

@@ -2,6 +2,7 @@
  * Built by tests/test_abi_c.py with gcc (no hipcc, no C++, no Python types).  Checks KAT-A of
  * R U R' U' from solved, plus U then U' (reward -1 / +1). */
 #define __HIP_PLATFORM_AMD__ 1
+#define _POSIX_C_SOURCE 200112L
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -16,8 +17,13 @@ int main(void) {
     const int64_t n = 5, pitch = 256;
     uint8_t *st, *act, *done, host[54 * 256], hdone[8], hact[16];
     float *reward, hrew[8];
-    if (rc_version() < 200) return 1;
+    if (rc_version() < 300) return 1;
+    /* a caller that skips rc_init gets RC_ENODEV, not a raw launch error */
+    if (rc_fill_solved((uint8_t *)host, n, pitch, 3, NULL) != RC_ENODEV || strlen(rc_last_error()) == 0) return 16;
     RC(rc_init(0));
+    char what[160];
+    RC(rc_describe_dispatch(RC_OP_STEP, 3, (int64_t)1 << 22, 0, RC_OUT_STATES | RC_OUT_DONE, RC_FMT_NONE, 0, what, (int)sizeof what));
+    if (strncmp(what, "k_step<Cube3,V=", 15) != 0 || !strstr(what, "POL=1")) { fprintf(stderr, "describe: %s\n", what); return 17; }
     CK(hipMalloc((void **)&st, 54 * pitch)); CK(hipMalloc((void **)&act, 16)); CK(hipMalloc((void **)&done, 16));
     CK(hipMalloc((void **)&reward, 16 * sizeof(float)));
     RC(rc_fill_solved(st, n, pitch, 3, NULL));
@@ -64,7 +70,21 @@ int main(void) {
     for (int a = 0; a < 12; ++a) if (pinned[288 + a] != 0) return 13;      /* no child of the solved cube is solved */
     /* per-call tuning override instead of any global knob */
     RC(rc_apply_moves_ex(st, st, act, n, pitch, pitch, 3, reward, done, NULL, RC_FMT_NONE, 0, NULL, 21));
+    RC(rc_facade_release(pinned));
     CK(hipHostFree(pinned));
+    /* hipHostRegister'ed memory: the kernel writes through the DEVICE alias of the buffer, the host polls the host address */
+    void *raw = NULL;
+    if (posix_memalign(&raw, 4096, 8192) != 0) return 18;
+    memset(raw, 0, 8192);
+    CK(hipHostRegister(raw, 8192, hipHostRegisterMapped));
+    RC(rc_fill_solved(st, n, pitch, 3, NULL));
+    RC(rc_facade_step(st, pitch, 3, 0, (uint8_t *)raw, 5u, 1, NULL));       /* U */
+    if (((uint8_t *)raw)[496] != 0) return 19;
+    RC(rc_facade_step(st, pitch, 3, 1, (uint8_t *)raw, 6u, 1, NULL));       /* U' -> solved */
+    if (((uint8_t *)raw)[496] != 1) return 20;
+    RC(rc_facade_release((const uint8_t *)raw));
+    CK(hipHostUnregister(raw));
+    free(raw);
     uint32_t status = 99;
     RC(rc_read_status(&status, NULL));
     if (status != 0) return 8;

@@ -11,7 +11,7 @@ Nothing from the reference is copied: the fixtures hold inputs (action sequences
 seeds, stub-model weights) and the outputs the reference computed for them.
 
     python -B tests/golden/make_golden.py            # everything
-    python -B tests/golden/make_golden.py mcts       # only the named groups (tables walks reset adi expand encode mcts)
+    python -B tests/golden/make_golden.py mcts       # only the named groups (tables walks reset adi expand encode mcts rollout adi_deepcube replay)
 
 Fixtures written (all small, np.savez_compressed):
   tables_333.npz   G1  tables as data (perm table, piece defs, hash weights, LUTs)
@@ -26,6 +26,8 @@ Fixtures written (all small, np.savez_compressed):
   rollout_333.npz  G9  greedy solve loops of train.py:183-193 / test.py:126-151 with the reference's own
                    DeepCube (model.py, small hidden dims, seeded init): actions taken and solve step
   adi_deepcube_333.npz G10 get_random_samples with the reference's DeepCube as the model
+  replay_333.npz   G11 the reference's ReplayBuffer (utils.py:203-270) fed by get_random_samples (G5's stub model): deque
+                   eviction, prioritised indices under seeded legacy draws, __getitem__ tuples, update(), DataLoader order
   mcts_333.npz     G8  the reference's MCTS (mcts.py) driven by a deterministic stub model and a
                    seeded `random`: simulations needed, returned action lists, root statistics;
                    plus reset(seed, 1000) end states for seeds 0..19 (test.py:166,279 style)
@@ -91,7 +93,9 @@ def main():
         golden_rollout(torch, env)
     if want("adi_deepcube"):
         golden_adi_deepcube(torch, env)
-    if groups and not (groups - {"mcts", "rollout", "adi_deepcube"}):
+    if want("replay"):
+        golden_replay(torch, env)
+    if groups and not (groups - {"mcts", "rollout", "adi_deepcube", "replay"}):
         return
     np.savez_compressed(
         os.path.join(HERE, "tables_333.npz"),
@@ -318,6 +322,71 @@ def golden_adi_deepcube(torch, env):
         target_policy=np.array([b["target_policy"] for b in buf], np.int64).reshape(shape),
         error=np.array([b["error"] for b in buf], np.float64).reshape(shape), **sd)
     print("adi_deepcube:", len(buf), "samples")
+
+
+def golden_replay(torch, env):
+    """G11: the reference's ReplayBuffer (utils.py:203-270) fed by get_random_samples with G5's stub model: eviction at
+    maxlen, prioritised sampling on the global legacy RNG, __getitem__ 5-tuples, update(), and the DataLoader order of
+    update_params (utils.py:296-303)."""
+    import utils as ref_utils
+    from torch.utils.data import DataLoader
+
+    g5 = np.load(os.path.join(HERE, "adi_333.npz"))
+    w_lin, b_lin = torch.tensor(g5["w"]), torch.tensor(g5["b"])
+
+    class StubModel(torch.nn.Module):
+        def forward(self, x):
+            if x.dim() == 2:
+                x = x.unsqueeze(0)
+            return (x.reshape(x.shape[0], -1) @ w_lin + b_lin).unsqueeze(-1), torch.zeros(x.shape[0], 12)
+
+    n_cubes, depth, temperature = 64, 30, float(g5["temperature"])
+    buf_size, sample_size = 1500, 256
+    rb = ref_utils.ReplayBuffer(buf_size, sample_size)
+    np.random.seed(int(g5["seed"]))
+    env.get_random_samples(rb, StubModel(), depth, n_cubes, temperature)          # 1920 samples into a deque of 1500
+    assert len(rb.memory) == buf_size
+    mem_cols = np.stack([cols_of(m["state"]) for m in rb.memory])
+    mem_err = np.array(rb.error_memory, np.float64)
+    out = {}
+    np.random.seed(31337)
+    rb.get_prioritized_sample()
+    out["idx1"] = np.asarray(rb.prioritized_idx, np.int64)
+    items = [rb[i] for i in range(len(rb))]
+    out["item_dtypes"] = np.array([str(t.dtype) for t in items[0]])
+    out["item_cols"] = np.stack([cols_of(it[0].numpy()) for it in items])
+    out["item_tv"] = np.array([it[1].item() for it in items], np.float32)
+    out["item_tp"] = np.array([it[2].item() for it in items], np.int64)
+    out["item_sc"] = np.array([it[3].item() for it in items], np.int64)
+    out["item_idx"] = np.array([it[4].item() for it in items], np.int64)
+    # the mini-batch order update_params sees: DataLoader(replay_buffer, batch_size, shuffle=True) under a torch seed
+    torch.manual_seed(4242)
+    out["loader_idx"] = np.concatenate([b[4].numpy() for b in DataLoader(rb, batch_size=100, shuffle=True)])
+    # update() as update_params does, then a second prioritised draw
+    upd_idx = out["idx1"][::3]
+    upd_err = (np.arange(len(upd_idx), dtype=np.float64) % 7 + 1) * 0.03125
+    for i, e in zip(upd_idx, upd_err):
+        rb.update(int(i), float(e))
+    np.random.seed(99)
+    rb.get_prioritized_sample()
+    out["idx2"] = np.asarray(rb.prioritized_idx, np.int64)
+    # more samples arrive (the deque drops its oldest 300), third draw
+    np.random.seed(7)
+    env.get_random_samples(rb, StubModel(), depth, 10, temperature)
+    np.random.seed(123)
+    rb.get_prioritized_sample()
+    out["idx3"] = np.asarray(rb.prioritized_idx, np.int64)
+    out["mem3_cols"] = np.stack([cols_of(m["state"]) for m in rb.memory])
+    out["mem3_err"] = np.array(rb.error_memory, np.float64)
+    # a buffer that is not full: every index, in order
+    small = ref_utils.ReplayBuffer(5000, 4000)
+    np.random.seed(5)
+    env.get_random_samples(small, StubModel(), 5, 8, temperature)
+    small.get_prioritized_sample()
+    out["small_idx"] = np.asarray(small.prioritized_idx, np.int64)
+    np.savez_compressed(os.path.join(HERE, "replay_333.npz"), buf_size=np.int64(buf_size), sample_size=np.int64(sample_size),
+                        mem_cols=mem_cols, mem_err=mem_err, upd_idx=upd_idx, upd_err=upd_err, **out)
+    print("replay:", len(out["idx1"]), "prioritised of", buf_size, "dtypes", list(out["item_dtypes"]))
 
 
 def golden_mcts(torch, cube_env, env):

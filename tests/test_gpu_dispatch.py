@@ -52,7 +52,7 @@ def walk_states(oracle, cs, n, depth, seed, threads=8):
 
 @pytest.mark.parametrize("cs", [3, 2])
 @pytest.mark.parametrize("v", [1, 2])
-@pytest.mark.parametrize("n,pitch", [(2500, None), (9000, 1024), (9000, 4096)])
+@pytest.mark.parametrize("n,pitch", [(2500, None), (9000, 512), (9000, 1024), (9000, 4096)])
 def test_expand_every_parts_value(ops, L, oracle, cs, v, n, pitch):
     S, A, SL = S_OF[cs], A_OF[cs], SL_OF[cs]
     states = walk_states(oracle, cs, n, 20, seed=n + v)
@@ -74,7 +74,7 @@ def test_expand_every_parts_value(ops, L, oracle, cs, v, n, pitch):
 
 @pytest.mark.parametrize("cs", [3, 2])
 @pytest.mark.parametrize("v", [1, 2])
-@pytest.mark.parametrize("n_walks,depth,pitch", [(1500, 6, None), (5000, 5, 1024), (5000, 5, 2048)])
+@pytest.mark.parametrize("n_walks,depth,pitch", [(1500, 6, None), (5000, 5, 512), (5000, 5, 1024), (5000, 5, 2048)])
 def test_adi_every_parts_value(ops, L, oracle, cs, v, n_walks, depth, pitch):
     exp = oracle.adi(cs, n_walks, depth, seed=77, stream=2, walk0=5, threads=8)
     for parts in PARTS[cs]:
@@ -104,6 +104,43 @@ def test_adi_every_parts_value(ops, L, oracle, cs, v, n_walks, depth, pitch):
             ops.adi_generate(n_walks, depth, cs, pt, "cuda", actions_in=a_in, variant=parts * 1000 + v, **b3)
             assert (untile(ops, b3["children"], n_walks, 2).transpose(2, 0, 1, 3) == exp["children"]).all(), parts
             assert (b3["actions_out"][:, :n_walks].cpu().numpy().T == exp["actions"]).all(), parts
+    assert L.read_status() == 0
+
+
+@pytest.mark.parametrize("cs", [3, 2])
+@pytest.mark.parametrize("v", [1, 2])
+def test_adi_depth_segments(ops, L, oracle, cs, v):
+    """Depth segments of the ADI kernel (a wave replays the moves of the earlier depths and emits only its own range): every
+    segment count 1..depth and beyond (clamped), alone and combined with parts, drawn and replayed moves -- all outputs
+    against the oracle (cube_env.py:177-194,212-236)."""
+    n_walks, depth = 3000, 7
+    exp = oracle.adi(cs, n_walks, depth, seed=91, stream=4, walk0=11, threads=8)
+    wp = None
+    for segs, parts in ((1, 1), (2, 1), (3, 2), (4, 1), (5, 3), (7, 1), (7, 6), (12, 1), (16, 2), (40, 1)):
+        pt, bufs = ops.adi_buffers(n_walks, depth, cs, "cuda", 1024, parents=True, parent_code=True, children=True, child_code=True)
+        for t in bufs.values():
+            t.fill_(7)
+        var = segs * 1000000 + parts * 1000 + v
+        ops.adi_generate(n_walks, depth, cs, pt, "cuda", seed=91, stream_id=4, walk_offset=11, variant=var, **bufs)
+        tag = (segs, parts)
+        assert (bufs["actions_out"][:, :n_walks].cpu().numpy().T == exp["actions"]).all(), tag
+        assert (untile(ops, bufs["parents"], n_walks, 1).transpose(1, 0, 2) == exp["parents"]).all(), tag
+        assert (untile(ops, bufs["parent_code"], n_walks, 1).transpose(1, 0, 2) == exp["parent_code"]).all(), tag
+        assert (untile(ops, bufs["children"], n_walks, 2).transpose(2, 0, 1, 3) == exp["children"]).all(), tag
+        assert (untile(ops, bufs["child_code"], n_walks, 2).transpose(2, 0, 1, 3) == exp["child_code"]).all(), tag
+        assert (bufs["child_solved"][..., :n_walks].cpu().numpy().transpose(2, 0, 1) == exp["child_solved"]).all(), tag
+        # the same through replayed moves and the code-only instantiation
+        wp = bufs["actions_out"].shape[1]
+        a_in = torch.zeros((depth, wp), dtype=torch.uint8, device="cuda")
+        a_in[:, :n_walks] = torch.from_numpy(np.ascontiguousarray(exp["actions"].T)).cuda()
+        pt, b2 = ops.adi_buffers(n_walks, depth, cs, "cuda", 1024, parent_code=True, child_code=True)
+        for t in b2.values():
+            t.fill_(7)
+        ops.adi_generate(n_walks, depth, cs, pt, "cuda", actions_in=a_in, variant=var, **b2)
+        assert (untile(ops, b2["parent_code"], n_walks, 1).transpose(1, 0, 2) == exp["parent_code"]).all(), tag
+        assert (untile(ops, b2["child_code"], n_walks, 2).transpose(2, 0, 1, 3) == exp["child_code"]).all(), tag
+        assert (b2["child_solved"][..., :n_walks].cpu().numpy().transpose(2, 0, 1) == exp["child_solved"]).all(), tag
+        assert (b2["actions_out"][:, :n_walks].cpu().numpy().T == exp["actions"]).all(), tag
     assert L.read_status() == 0
 
 
@@ -233,7 +270,7 @@ def _random_shapes(seed, count):
     out = []
     for _ in range(count):
         n = int(rng.choice(special)) if rng.random() < 0.5 else int(rng.integers(1, 9000))
-        pitch = None if n <= 1024 or rng.random() < 0.4 else int(rng.choice([1024, 2048, 4096]))
+        pitch = None if n <= 1024 or rng.random() < 0.4 else int(rng.choice([512, 1024, 2048, 4096]))
         out.append((n, pitch, int(rng.choice([3, 2])), int(rng.choice([0, 1, 2])), int(rng.choice([0, 1, 2, 3, 6]))))
     return out
 

@@ -689,3 +689,128 @@ def test_vec_env_debug_action_check_and_clone(mod):
     assert torch.equal(twin.sim_cube, lean.sim_cube)
     with pytest.raises(ValueError):
         env.step(torch.zeros(63, dtype=torch.uint8, device="cuda"))   # wrong length is refused on the fast path too
+
+
+# ----------------------------------------------------------------------------- N1: tensor replay sink (fixture G11)
+def _g11_buffer(rc, g, upto=None):
+    """TensorReplayBuffer holding exactly what the reference's ReplayBuffer held in fixture G11 after the first
+    get_random_samples call (its 1500 newest of 1920 samples), appended as reference-style tensors."""
+    buf = rc.TensorReplayBuffer(int(g["buf_size"]), int(g["sample_size"]), cube_size=3, device="cuda")
+    return buf
+
+
+def test_tensor_replay_buffer_matches_reference_class(golden):
+    """Fixture G11 = the reference's ReplayBuffer (utils.py:203-270) fed by its own get_random_samples with G5's stub model.
+    The tensor sink, fed by the PRODUCT's get_random_samples under the same global seed, must hold the same samples after the
+    deque eviction, draw the same prioritised indices under the same legacy-RNG seeds, return the same 5-tuples (values and
+    dtypes), visit them in the DataLoader's order, and follow update() and later appends exactly."""
+    import rubiks_cube_solver_amd as rc
+    g, g5 = golden("replay_333"), golden("adi_333")
+    w, b = torch.tensor(g5["w"]), torch.tensor(g5["b"])
+
+    class Stub(torch.nn.Module):
+        def forward(self, x):
+            if x.dim() == 2:
+                x = x.unsqueeze(0)
+            return (x.reshape(x.shape[0], -1).float().cpu() @ w + b).unsqueeze(-1), torch.zeros(x.shape[0], 12)
+
+    env = rc.make_env(torch.device("cpu"), 3)
+    rb = rc.TensorReplayBuffer(int(g["buf_size"]), int(g["sample_size"]), cube_size=3, device="cuda")
+    np.random.seed(int(g5["seed"]))
+    env.get_random_samples(rb, Stub(), 30, 64, float(g5["temperature"]))          # 1920 samples into a ring of 1500
+    n = rb.size
+    assert n == int(g["buf_size"])
+    phys = torch.from_numpy(rb._phys(np.arange(n))).cuda()
+    assert (rb.code[phys].cpu().numpy() == g["mem_cols"]).all()                    # same samples survive, oldest first
+    got_err = rb.error_memory[rb._phys(np.arange(n))]
+    assert np.allclose(got_err, g["mem_err"], rtol=0, atol=2e-6)                   # fp32 stub on the device vs the reference's CPU dot
+    # from here on the DRAWS are what is tested: give both sides bit-identical probabilities
+    rb.error_memory[rb._phys(np.arange(n))] = g["mem_err"]
+    np.random.seed(31337)
+    idx1 = rb.get_prioritized_sample()
+    assert (idx1 == g["idx1"]).all() and len(rb) == int(g["sample_size"])
+    items = [rb[i] for i in range(len(rb))]
+    assert [str(t.dtype) for t in items[0]] == list(g["item_dtypes"])
+    assert (torch.stack([it[0] for it in items]).argmax(-1).cpu().numpy() == g["item_cols"]).all()
+    assert all(int(it[0].sum()) == 20 and tuple(it[0].shape) == (20, 24) for it in items[:8])
+    tv = torch.stack([it[1] for it in items]).cpu().numpy()
+    solved = g["item_tv"] == 1.0
+    assert (tv[solved] == 1.0).all() and np.allclose(tv, g["item_tv"], rtol=0, atol=2e-6)
+    assert (torch.stack([it[2] for it in items]).cpu().numpy() == g["item_tp"]).all()
+    assert (torch.stack([it[3] for it in items]).cpu().numpy() == g["item_sc"]).all()
+    assert (torch.stack([it[4] for it in items]).cpu().numpy() == g["item_idx"]).all()
+    # DataLoader(replay_buffer, batch_size, shuffle=True) of update_params (utils.py:296-303), and the batched iterator
+    from torch.utils.data import DataLoader
+    torch.manual_seed(4242)
+    assert (np.concatenate([bt[4].cpu().numpy() for bt in DataLoader(rb, batch_size=100, shuffle=True)]) == g["loader_idx"]).all()
+    torch.manual_seed(4242)
+    seen = []
+    for st, v, pol, sc, mem in rb.batches(100, shuffle=True, dtype=torch.bfloat16):
+        assert st.dtype == torch.bfloat16 and st.shape[1:] == (20, 24) and float(st.float().sum()) == 20 * st.shape[0]
+        where = {int(m): k for k, m in enumerate(g["item_idx"])}
+        rows = [where[int(m)] for m in mem.cpu().numpy()]
+        assert (st.float().argmax(-1).cpu().numpy() == g["item_cols"][rows]).all() and (sc.cpu().numpy() == g["item_sc"][rows]).all()
+        seen.append(mem.cpu().numpy())
+    assert (np.concatenate(seen) == g["loader_idx"]).all()
+    # update() then a second draw; scalar and batched forms
+    half = len(g["upd_idx"]) // 2
+    for i, e in zip(g["upd_idx"][:half], g["upd_err"][:half]):
+        rb.update(int(i), float(e))
+    rb.update(torch.from_numpy(g["upd_idx"][half:]), torch.from_numpy(g["upd_err"][half:]))
+    np.random.seed(99)
+    assert (rb.get_prioritized_sample() == g["idx2"]).all()
+    # more samples arrive: the oldest 300 leave, indices shift as in a deque
+    np.random.seed(7)
+    env.get_random_samples(rb, Stub(), 30, 10, float(g5["temperature"]))
+    n = rb.size
+    phys = torch.from_numpy(rb._phys(np.arange(n))).cuda()
+    assert (rb.code[phys].cpu().numpy() == g["mem3_cols"]).all()
+    assert np.allclose(rb.error_memory[rb._phys(np.arange(n))], g["mem3_err"], rtol=0, atol=2e-6)
+    rb.error_memory[rb._phys(np.arange(n))] = g["mem3_err"]
+    np.random.seed(123)
+    assert (rb.get_prioritized_sample() == g["idx3"]).all()
+    # a buffer that is not full returns every index in order; single reference-style dicts are accepted too
+    small = rc.TensorReplayBuffer(5000, 4000, cube_size=3, device="cuda")
+    np.random.seed(5)
+    env.get_random_samples(small, Stub(), 5, 8, float(g5["temperature"]))
+    assert (small.get_prioritized_sample() == g["small_idx"]).all() and small.size == 40
+    ref_style = []
+    np.random.seed(5)
+    env.get_random_samples(ref_style, Stub(), 5, 8, float(g5["temperature"]))
+    one = rc.TensorReplayBuffer(64, 64, cube_size=3, device="cuda")
+    for smp in ref_style:
+        one.append(smp)
+    one.get_prioritized_sample()
+    assert torch.equal(one.code[:40], small.code[:40]) and torch.equal(one.target_policy[:40], small.target_policy[:40])
+    assert np.array_equal(one.error_memory[:40], small.error_memory[:40]) and torch.equal(one[3][0], small[3][0])
+
+
+def test_tensor_replay_buffer_222_and_wraparound():
+    """2x2x2 samples ([7,21] float64 one-hots, transposed convention cube_env.py:142-147) through the sink, with the ring
+    wrapping several times in one append and across appends; every stored sample equals the dict adapter's."""
+    import rubiks_cube_solver_amd as rc
+
+    class Stub(torch.nn.Module):
+        def forward(self, x):
+            if x.dim() == 2:
+                x = x.unsqueeze(0)
+            f = x.reshape(x.shape[0], -1).float().cpu()
+            return (f @ torch.linspace(-0.3, 0.4, f.shape[1]) + 0.05).unsqueeze(-1), torch.zeros(x.shape[0], 6)
+
+    env = rc.make_env(torch.device("cpu"), 2)
+    ref_style, rb = [], rc.TensorReplayBuffer(37, 16, cube_size=2, device="cuda")
+    for seed, (depth, cubes) in enumerate(((6, 4), (9, 11), (3, 2))):              # 24, 99 (> capacity), 6 samples
+        np.random.seed(seed)
+        env.get_random_samples(ref_style, Stub(), depth, cubes, 0.5)
+        np.random.seed(seed)
+        env.get_random_samples(rb, Stub(), depth, cubes, 0.5)
+        keep = ref_style[-37:]
+        assert rb.size == len(keep)
+        np.random.seed(1000 + seed)
+        idx = rb.get_prioritized_sample()
+        for j, i in enumerate(idx[:16]):
+            st, tv, tp, sc, mi = rb[j]
+            smp = keep[int(i)]
+            assert st.dtype == torch.float64 and (st.cpu().numpy() == smp["state"]).all()
+            assert float(tv) == np.float32(smp["target_value"]) and int(tp) == smp["target_policy"] and int(sc) == smp["scramble_count"]
+            assert int(mi) == int(i) and rb.error_memory[rb._phys(int(i))] == smp["error"]

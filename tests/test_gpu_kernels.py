@@ -92,7 +92,7 @@ def test_library_tables_match_package(L):
 
 
 @pytest.mark.parametrize("cs", CS)
-@pytest.mark.parametrize("n,pitch", [(1, None), (3, None), (4, 16), (63, None), (257, 1024), (1000, None), (4099, 1024),
+@pytest.mark.parametrize("n,pitch", [(1, None), (3, None), (4, 16), (63, None), (257, 1024), (1000, None), (4099, 1024), (4099, 512),
                                      (40000, None), (40000, 2048)])
 def test_fill_and_is_solved(ops, oracle, cs, n, pitch):
     st = ops.alloc_states(n, cs, "cuda", pitch)
@@ -143,7 +143,7 @@ def test_apply_moves_vs_oracle(ops, L, oracle, cs, variant, n, pitch):
 
 @pytest.mark.parametrize("cs", CS)
 @pytest.mark.parametrize("fmt_name", ["U8", "F16", "BF16", "F32"])
-@pytest.mark.parametrize("n,pitch", [(1, None), (6, None), (1023, None), (1024, None), (1025, None), (5000, None), (5000, 1024)])
+@pytest.mark.parametrize("n,pitch", [(1, None), (6, None), (1023, None), (1024, None), (1025, None), (5000, None), (5000, 1024), (5000, 512)])
 def test_apply_moves_dense_onehot(ops, L, oracle, cs, fmt_name, n, pitch):
     fmt = getattr(L, "FMT_" + fmt_name)
     R, C = RC_OF[cs]
@@ -232,7 +232,7 @@ def test_golden_encode_arbitrary_colourings(ops, L, golden):
 
 
 @pytest.mark.parametrize("cs", CS)
-@pytest.mark.parametrize("n,pitch", [(1, None), (37, None), (512, None), (4096, None), (4096, 1024), (70000, None), (70000, 2048)])
+@pytest.mark.parametrize("n,pitch", [(1, None), (37, None), (512, None), (4096, None), (4096, 1024), (4096, 512), (70000, None), (70000, 2048)])
 def test_expand_children(ops, L, oracle, cs, n, pitch):
     S, A, SL = S_OF[cs], A_OF[cs], SL_OF[cs]
     if pitch is not None:

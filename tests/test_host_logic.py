@@ -76,7 +76,7 @@ def test_abi_exports_every_declared_symbol():
     assert len(declared) >= 15
     for name in declared:
         assert hasattr(L, name), name
-    assert L.rc_version() >= 200 and len(declared) >= 21
+    assert L.rc_version() >= 300 and len(declared) >= 23 and {"rc_describe_dispatch", "rc_facade_release"} <= declared
     assert L.rc_last_error() == b"" or isinstance(L.rc_last_error(), bytes)
     # include/rubiktree.h <-> librubiktree.so (host-side trees of the lockstep search)
     from rubiks_cube_solver_amd import _tree
@@ -98,6 +98,36 @@ def test_abi_tables_equal_package_tables():
         assert t["dims"][:2] == (p.n_stickers, p.n_actions)
     assert _lib.lib().rc_get_tables(4, None, None, None, None, None, None, None) == -1
     assert b"cube_size" in _lib.lib().rc_last_error()
+
+
+def test_dispatch_description_and_enodev_without_gpu():
+    """rc_describe_dispatch runs the library's own dispatch functions on the host (no GPU needed): the shapes the bench labels
+    its records with.  Launching entry points return RC_ENODEV while rc_init has not succeeded for the current device."""
+    from rubiks_cube_solver_amd import _lib as L
+    st = L.OUT_STATES | L.OUT_DONE
+    assert L.describe(L.OP_STEP, 3, 1 << 22, outputs=st).startswith("k_step<Cube3,V=2,move,store,POL=1> grid=8192")
+    assert "POL=2" in L.describe(L.OP_STEP, 3, 1 << 24, outputs=st) and "POL=0" in L.describe(L.OP_STEP, 3, 1 << 20, outputs=st)
+    assert "POL=0" in L.describe(L.OP_STEP, 3, 1 << 22, outputs=st | L.OUT_INPLACE)             # 226 MB in place: resident
+    assert "POL=3" in L.describe(L.OP_STEP, 3, 1 << 22, outputs=st | L.OUT_INPLACE, fmt=L.FMT_CODE)   # + 84 MB of code: streamed past
+    assert "V=2,move,store,code,POL=1" in L.describe(L.OP_STEP, 3, 1 << 22, outputs=st | L.OUT_REWARD, fmt=L.FMT_CODE)
+    assert L.describe(L.OP_STEP, 2, 1 << 22, outputs=st).startswith("k_step<Cube2,")
+    assert L.describe(L.OP_STEP, 3, 1 << 20, outputs=st, fmt=L.FMT_BF16).startswith("k_step_dense<Cube3,bf16,move,store,TILE=256> grid=4096")
+    assert L.describe(L.OP_STEP, 3, 4096, outputs=0, fmt=L.FMT_F32).startswith("k_step_dense<Cube3,f32,encode,TILE=64>")
+    assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 20, fmt=L.FMT_F32).startswith("k_code_to_dense<Cube3,f32,TILE=256> grid=2048")
+    assert L.describe(L.OP_EXPAND, 3, 1 << 20, outputs=L.OUT_STATES | L.OUT_FLAGS).startswith("k_expand<Cube3,V=2> parts=1 grid=2048")
+    assert L.describe(L.OP_ADI, 3, 100000, 30, outputs=L.OUT_STATES | L.OUT_FLAGS).startswith("k_adi<Cube3,V=2> parts=1 segs=1 grid=196")
+    assert L.describe(L.OP_ADI, 3, 100000, 30, outputs=L.OUT_CODE | L.OUT_FLAGS).startswith("k_adi<Cube3,V=2,code> parts=1 segs=3 grid=588")
+    assert "segs=5 " in L.describe(L.OP_ADI, 3, 100000, 5, outputs=L.OUT_CODE, variant=9001001)       # clamped to the depth
+    assert "V=1," in L.describe(L.OP_STEP, 3, 1 << 22, outputs=st, variant=1) and "POL=0" in L.describe(L.OP_STEP, 3, 1 << 22, outputs=st, variant=20)
+    with pytest.raises(L.RubikHipError):
+        L.describe(99, 3, 10)
+    with pytest.raises(L.RubikHipError):
+        L.describe(L.OP_ADI, 3, 10, 0)
+    if not torch.cuda.is_available():
+        lib = L.lib()
+        assert lib.rc_fill_solved(None, 1, 256, 3, None) == -3 and b"rc_init" in lib.rc_last_error() or b"device" in lib.rc_last_error()
+        out = ctypes.c_uint32(0)
+        assert lib.rc_read_status(ctypes.byref(out), None) == -3
 
 
 def test_no_cpu_fallback_without_gpu():

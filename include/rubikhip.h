@@ -164,6 +164,8 @@ int rc_encode(const uint8_t *st, int64_t n_cubes, int64_t pitch, int cube_size, 
 /* Dense one-hot [n][R][C] from a compact code buffer (RC_FMT_CODE layout). fmt = U8/F16/BF16/F32. */
 int rc_onehot_from_code(const uint8_t *code, int64_t n_cubes, int64_t code_pitch, int cube_size,
                         void *onehot, int fmt, void *stream);
+int rc_onehot_from_code_ex(const uint8_t *code, int64_t n_cubes, int64_t code_pitch, int cube_size,
+                           void *onehot, int fmt, void *stream, int variant);
 
 /* All A children of every cube.  Outputs use one tiling (pitch_out, tiles = ceil(n / pitch_out)
  * when n > pitch_out, else 1), child-major:
@@ -249,7 +251,9 @@ const char *rc_last_error(void);
  *   tens       row-traffic policy of the step kernel: 1 stream in / stream out, 2 default-cached,
  *              3 stream in / keep the output in the Infinity Cache, 4 state default-cached / side outputs streamed
  *   thousands  (2 digits) parts per walk group for expansion / ADI (1..A, rounded up to a divisor of A)
- *   100000s    dense one-hot tile: 1 -> 64, 2 -> 256 cubes per workgroup
+ *   100000s    dense one-hot writer: 1 -> 64-cube tiles, 2 -> 256-cube tiles (256-thread workgroups), 3 -> the wide form of
+ *              rc_onehot_from_code (960-thread workgroups sweeping contiguous tile ranges; 3x3x3, the default from 2^17 cubes;
+ *              the thousands field then gives the wanted workgroup count / 16)
  *   millions   (2 digits) depth segments per walk group of the ADI kernel (1..16, clamped to depth) */
 
 #ifdef __cplusplus

@@ -45,6 +45,7 @@ def _declare(L):
     L.rc_is_solved.argtypes = [vp, i64, i64, i32, vp, vp, vp]
     L.rc_encode.argtypes = [vp, i64, i64, i32, vp, i32, i64, vp]
     L.rc_onehot_from_code.argtypes = [vp, i64, i64, i32, vp, i32, vp]
+    L.rc_onehot_from_code_ex.argtypes = [vp, i64, i64, i32, vp, i32, vp, i32]
     L.rc_expand_children.argtypes = [vp, i64, i64, i32, vp, vp, vp, i64, vp]
     L.rc_expand_children_ex.argtypes = [vp, i64, i64, i32, vp, vp, vp, i64, vp, i32]
     L.rc_adi_generate.argtypes = [u64, u64, i64, i64, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -56,7 +57,7 @@ def _declare(L):
     for name in ("rc_init", "rc_get_tables", "rc_fill_solved", "rc_apply_moves", "rc_apply_moves_ex", "rc_facade_step", "rc_facade_steps", "rc_facade_expand", "rc_scramble",
                  "rc_legacy_scramble_actions", "rc_is_solved", "rc_encode", "rc_onehot_from_code", "rc_expand_children",
                  "rc_expand_children_ex", "rc_adi_generate", "rc_adi_generate_ex", "rc_adi_targets", "rc_read_status",
-                 "rc_describe_dispatch", "rc_facade_release"):
+                 "rc_describe_dispatch", "rc_facade_release", "rc_onehot_from_code_ex"):
         getattr(L, name).restype = i32
 
 

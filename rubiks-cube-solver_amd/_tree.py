@@ -58,6 +58,11 @@ class NativeTrees:
 
     def __init__(self, n_roots, n_actions, n_slots, cpuct, virtual_loss, value_min, rngs=None, threads=None):
         import random
+        if int(np.__version__.split(".")[0]) < 2:
+            # the native PUCT computes c * P * sqrt(N) / (1 + n) + W - L in float32, which is what the reference's expression
+            # evaluates to under numpy >= 2 (NEP 50: python float * np.float32 stays float32); numpy 1.x promotes it to float64
+            raise RuntimeError("the native search trees reproduce numpy >= 2 scalar arithmetic; with numpy 1.x use "
+                               "BatchedMCTS(native=False)")
         self.L = tree_lib()
         self.n, self.A, self.slots = int(n_roots), int(n_actions), int(n_slots)
         self.h = self.L.rc_tree_create(self.n, self.A, self.slots, float(cpuct), float(virtual_loss), float(value_min))
@@ -122,6 +127,9 @@ class NativeTrees:
     def solution(self, r):
         buf = np.empty(4096, np.uint8)
         k = self.L.rc_tree_solution(self.h, int(r), _p(buf), len(buf))
+        if k > len(buf):                                  # the call reports the full length: fetch again with room for it
+            buf = np.empty(k, np.uint8)
+            k = self.L.rc_tree_solution(self.h, int(r), _p(buf), len(buf))
         return None if k < 0 else [int(a) for a in buf[:k]]
 
     def sims_used(self):

@@ -207,6 +207,40 @@ __device__ __forceinline__ void apply_move(const Pk<V> (&in)[T::S], const Pk<V> 
     });
 }
 
+// The same move IN PLACE, orbit by orbit: corner stickers only ever receive corner stickers and edge stickers edge stickers
+// (centres stay), so the new values of one orbit (24 registers per pack) are built and written back before the other orbit is
+// touched -- peak live state 54 + 24 instead of 54 + 54 registers per pack.  Used where the register budget is tight (the
+// 960-thread dense kernels: 128 VGPRs per lane).
+template <class T, int I>
+constexpr bool in_orbit(int orbit) {   // orbit 0: corner stickers, 1: edge stickers (3x3x3); the 2x2x2 has corners only
+    if (T::SIZE == 2) return orbit == 0;
+    const int k = I % 9;
+    return orbit == 0 ? (k == 0 || k == 2 || k == 6 || k == 8) : (k == 1 || k == 3 || k == 5 || k == 7);
+}
+template <class T, int V>
+__device__ __forceinline__ void apply_move_inplace(Pk<V> (&s)[T::S], const Pk<V> (&m)[T::A]) {
+    sfor<2>([&](auto oc) {
+        constexpr int orbit = decltype(oc)::value;
+        Pk<V> t[T::S];                                             // only this orbit's entries are ever touched
+        sfor<T::S>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (in_orbit<T, i>(orbit)) {
+                Pk<V> o = s[i];
+                sfor<T::A>([&](auto ac) {
+                    constexpr int a = decltype(ac)::value;
+                    constexpr int src = kPerm<T>.v[a][i];
+                    if constexpr (src != i) o = sel(m[a], s[src], o);
+                });
+                t[i] = o;
+            }
+        });
+        sfor<T::S>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (in_orbit<T, i>(orbit)) s[i] = t[i];
+        });
+    });
+}
+
 // child by a FIXED action: pure register renaming
 template <class T, int V, int A_>
 __device__ __forceinline__ void fixed_move(const Pk<V> (&in)[T::S], Pk<V> (&out)[T::S]) {
@@ -345,6 +379,30 @@ __device__ __forceinline__ Pk<V> lut72(Pk<V> h) {
     return r;
 }
 
+// Code look-up indexed by TWO colours (rc_tables.h epair_dw / cpair_dw, tables.py pair_tables): row = second colour c1,
+// byte inside the row = first colour c0.  Colours are 0..5, so c0 is a v_perm selector as it stands (no hash, no AND), the
+// six rows are six 8-entry v_perm look-ups, and the row is chosen by a select tree on the bits of c1 whose three masks are
+// v_perm look-ups of c1 as well: 6 + 3 v_perm + 5 v_bfi instead of hash + lut72's ~25-32 operations.
+//   TABLE < 0 : edges, epair[c1][c0] = ecode[c0 + 10 c1] -- the hash is injective in (c0, c1): exact for ANY colouring;
+//   TABLE >= 0: corners of states REACHABLE from solved, where (c0, c1) of a slot read in a fixed order determines the third
+//               colour: cpair[TABLE][c1][c0] = ccode[c0 + 2 c1 + 10 c2(c0, c1)], zeros where the reference's table is silent.
+template <class T, int V, int TABLE>
+__device__ __forceinline__ Pk<V> lut_pair(Pk<V> c0, Pk<V> c1) {
+    Pk<V> g[6];
+    sfor<6>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr uint32_t lo = TABLE < 0 ? T::epair_dw[k][0] : T::cpair_dw[TABLE < 0 ? 0 : TABLE][k][0];
+        constexpr uint32_t hi = TABLE < 0 ? T::epair_dw[k][1] : T::cpair_dw[TABLE < 0 ? 0 : TABLE][k][1];
+        if constexpr (hi == 0 && lo == 0) g[k] = splat<V>(0);
+        else g[k] = perm<V>(hi, lo, c0);
+    });
+    const Pk<V> b0 = perm<V>(0xFF00FF00u, 0xFF00FF00u, c1);    // 0xff where bit 0 of c1 is set
+    const Pk<V> b1 = perm<V>(0xFFFF0000u, 0xFFFF0000u, c1);    //                bit 1
+    const Pk<V> b2 = perm<V>(0xFFFFFFFFu, 0x00000000u, c1);    //                bit 2
+    const Pk<V> a0 = sel(b0, g[1], g[0]), a1 = sel(b0, g[3], g[2]), a2 = sel(b0, g[5], g[4]);
+    return sel(b2, a2, sel(b1, a1, a0));
+}
+
 template <class T, int V, int SLOT>
 __device__ __forceinline__ Pk<V> encode_slot(const Pk<V> (&s)[T::S]) {
     if constexpr (SLOT < T::NC) {
@@ -354,12 +412,10 @@ __device__ __forceinline__ Pk<V> encode_slot(const Pk<V> (&s)[T::S]) {
         const Pk<V> h = shl_add(c2, 1, shl_add(c2, 3, shl_add(c1, 1, c0)));
         return lut72<T, V, true>(h);
     } else {
-        // h = c0 + 10*c1          (py333.py:168,226); max 55
+        // edge_pieceInds[c0 + 10*c1] (py333.py:168,226) read as a table of the two colours: exact for any colouring
         constexpr int e = SLOT - T::NC;
         constexpr int i0 = T::edef[e][0], i1 = T::edef[e][1];
-        const Pk<V> c0 = s[i0], c1 = s[i1];
-        const Pk<V> h = shl_add(c1, 1, shl_add(c1, 3, c0));
-        return lut72<T, V, false>(h);
+        return lut_pair<T, V, -1>(s[i0], s[i1]);
     }
 }
 
@@ -431,7 +487,9 @@ struct FamilyCodes {
     Pk<V> e[T::NE > 0 ? T::NE : 1][2];
 };
 
-template <class T, int V>
+// REACH: the state is reachable from the solved cube (ADI walks), so corner codes come from the two-colour tables too;
+// otherwise (rc_expand_children: any colouring) corners keep the literal hash + 72-entry table.
+template <class T, int V, bool REACH>
 __device__ __forceinline__ void family_codes(const Pk<V> (&s)[T::S], FamilyCodes<T, V> &f) {
     sfor<T::NC>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
@@ -441,8 +499,12 @@ __device__ __forceinline__ void family_codes(const Pk<V> (&s)[T::S], FamilyCodes
                 constexpr int j0 = id / 2, r0 = j0 == 0 ? 1 : 0, r1 = j0 == 2 ? 1 : 2;
                 constexpr int j1 = id % 2 ? r1 : r0, j2 = id % 2 ? r0 : r1;
                 constexpr int i0 = T::cdef[q][j0], i1 = T::cdef[q][j1], i2 = T::cdef[q][j2];
-                const Pk<V> h = shl_add(s[i2], 1, shl_add(s[i2], 3, shl_add(s[i1], 1, s[i0])));   // c0 + 2 c1 + 10 c2
-                f.c[q][id] = lut72<T, V, true>(h);
+                if constexpr (REACH) {
+                    f.c[q][id] = lut_pair<T, V, T::cpair_id[q][id]>(s[i0], s[i1]);
+                } else {
+                    const Pk<V> h = shl_add(s[i2], 1, shl_add(s[i2], 3, shl_add(s[i1], 1, s[i0])));   // c0 + 2 c1 + 10 c2
+                    f.c[q][id] = lut72<T, V, true>(h);
+                }
             }
         });
     });
@@ -452,8 +514,7 @@ __device__ __forceinline__ void family_codes(const Pk<V> (&s)[T::S], FamilyCodes
             constexpr int id = decltype(ic)::value;
             if constexpr (edge_pair_used<T>(q, id)) {
                 constexpr int i0 = T::edef[q][id], i1 = T::edef[q][1 - id];
-                const Pk<V> h = shl_add(s[i1], 1, shl_add(s[i1], 3, s[i0]));                        // c0 + 10 c1
-                f.e[q][id] = lut72<T, V, false>(h);
+                f.e[q][id] = lut_pair<T, V, -1>(s[i0], s[i1]);                                       // ecode[c0 + 10 c1]
             }
         });
     });
@@ -524,11 +585,13 @@ __device__ __forceinline__ uint32_t onehot_bits4(const uint8_t *lds_code, int tp
 // 240 threads cover exactly 2 / 4 / 8 whole cubes per pass and thread t ALWAYS writes the same chunk of a cube: its one-hot
 // row(s) and columns are fixed before the loop, a pass costs one LDS byte read, a few compares and one 16-byte store
 // (the generic loop below re-derives cube / row / column from the element index with two divisions per store).
-template <class T, class E>
+// NT = writer threads per pass, a multiple of 120 (so that it is a multiple of CPC for every format): 240 of a 256-thread
+// workgroup, 960 of the wide 960-thread form (15 waves sweeping ONE contiguous stream per compute unit).
+template <class T, class E, int NT = 240>
 __device__ __forceinline__ void dense_write_333(const uint8_t *lds_code, int tp, E *out, int ncubes, int tid) {
-    static_assert(T::SIZE == 3 && T::R * T::C == 480 && T::C % 4 == 0);
-    constexpr int EPT = 16 / (int)sizeof(E), CPC = 480 / EPT, CPP = 240 / CPC;   // elements per chunk, chunks per cube, cubes per pass
-    if (tid >= 240) return;
+    static_assert(T::SIZE == 3 && T::R * T::C == 480 && T::C % 4 == 0 && NT % 120 == 0);
+    constexpr int EPT = 16 / (int)sizeof(E), CPC = 480 / EPT, CPP = NT / CPC;   // elements per chunk, chunks per cube, cubes per pass
+    if (tid >= NT) return;
     const int sub = tid / CPC, k = tid - sub * CPC;
     const __amdgpu_buffer_rsrc_t srd = make_srd(out);                           // `out` is workgroup-uniform
     uint32_t off = (uint32_t)sub * 480u * (uint32_t)sizeof(E) + (uint32_t)k * 16u;

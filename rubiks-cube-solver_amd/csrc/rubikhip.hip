@@ -22,6 +22,7 @@
 
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/rubikhip.h"
@@ -196,6 +197,42 @@ constexpr int kDenseBlock = 256;
 // the chip: 4096 cubes are 64 workgroups at TILE = 64 but only 4 at TILE = 1024.
 // LDS row pitch TILE + 4 bytes: rows fall on different banks for the byte reads of dense_write.
 
+// One wave's share of a dense step: the 4 cubes of this lane (tile0 + lo ..) are loaded, moved, stored, flagged and encoded,
+// their codes land in the LDS code tile `lds_code` ([SLOTS][tp] bytes).  tile0 is wave-uniform and a multiple of 256.
+template <class T, bool MOVE, bool STORE>
+__device__ __forceinline__ void dense_produce(const StepArgs &a, int64_t tile0, uint32_t lo, uint8_t *lds_code, int tp) {
+    const int64_t n0 = tile0 + lo;
+    Pk<1> s[T::S];
+    {
+        const __amdgpu_buffer_rsrc_t r = make_srd(a.in + tile_off(tile0, a.pitch_in, a.sh_in, T::S));
+        const uint32_t rs = (uint32_t)a.pitch_in;
+#pragma unroll
+        for (int i = 0; i < T::S; ++i) s[i] = bld<1, kAuxCached>(r, lo, i * rs);
+    }
+    if constexpr (MOVE) {
+        const Pk<1> act = ld_tail<1>(a.actions, n0, a.n, 0);
+        Pk<1> m[T::A];
+        const Pk<1> bad = action_masks<T, 1>(act, m);
+        if (any_bad<1>(bad, n0, a.n)) atomicOr(&g_status, RC_STATUS_BAD_ACTION);
+        apply_move_inplace<T, 1>(s, m);
+    }
+    if constexpr (STORE) {
+        const __amdgpu_buffer_rsrc_t r = make_srd(a.out + tile_off(tile0, a.pitch_out, a.sh_out, T::S));
+        const uint32_t rs = (uint32_t)a.pitch_out;
+#pragma unroll
+        for (int i = 0; i < T::S; ++i) bst<1, kAuxCached>(r, lo, i * rs, s[i]);
+    }
+    if (a.done != nullptr || a.reward != nullptr) {
+        const Pk<1> dn = done_bytes(unsolved<T, 1>(s));
+        if (a.done) st_tail<1>(a.done, n0, a.n, dn);
+        if (a.reward) store_reward<1>(a.reward, n0, a.n, dn);
+    }
+    Pk<1> c[T::SLOTS];
+    encode<T, 1>(s, c);
+#pragma unroll
+    for (int p = 0; p < T::SLOTS; ++p) *reinterpret_cast<uint32_t *>(lds_code + p * tp + lo) = c[p].d[0];
+}
+
 template <class T, class E, bool MOVE, bool STORE, int TILE>
 __global__ void __launch_bounds__(kDenseBlock) k_step_dense(StepArgs a, E *dense) {
     constexpr int TP = TILE + 4;
@@ -203,46 +240,12 @@ __global__ void __launch_bounds__(kDenseBlock) k_step_dense(StepArgs a, E *dense
     const uint32_t lo = threadIdx.x * 4;
     // grid-stride over tiles: large batches run a capped grid (launch_dense_t), every workgroup a few tiles in turn
     for (int64_t tile0 = (int64_t)blockIdx.x * TILE; tile0 < a.n; tile0 += (int64_t)gridDim.x * TILE) {
-    const int64_t n0 = tile0 + lo;
-    if (lo < TILE && n0 < a.n) {
-        Pk<1> s[T::S];
-        {
-            const __amdgpu_buffer_rsrc_t r = make_srd(a.in + tile_off(tile0, a.pitch_in, a.sh_in, T::S));
-            const uint32_t rs = (uint32_t)a.pitch_in;
-#pragma unroll
-            for (int i = 0; i < T::S; ++i) s[i] = bld<1, kAuxCached>(r, lo, i * rs);
-        }
-        if constexpr (MOVE) {
-            const Pk<1> act = ld_tail<1>(a.actions, n0, a.n, 0);
-            Pk<1> m[T::A];
-            const Pk<1> bad = action_masks<T, 1>(act, m);
-            if (any_bad<1>(bad, n0, a.n)) atomicOr(&g_status, RC_STATUS_BAD_ACTION);
-            Pk<1> o[T::S];
-            apply_move<T, 1>(s, m, o);
-#pragma unroll
-            for (int i = 0; i < T::S; ++i) s[i] = o[i];
-        }
-        if constexpr (STORE) {
-            const __amdgpu_buffer_rsrc_t r = make_srd(a.out + tile_off(tile0, a.pitch_out, a.sh_out, T::S));
-            const uint32_t rs = (uint32_t)a.pitch_out;
-#pragma unroll
-            for (int i = 0; i < T::S; ++i) bst<1, kAuxCached>(r, lo, i * rs, s[i]);
-        }
-        if (a.done != nullptr || a.reward != nullptr) {
-            const Pk<1> dn = done_bytes(unsolved<T, 1>(s));
-            if (a.done) st_tail<1>(a.done, n0, a.n, dn);
-            if (a.reward) store_reward<1>(a.reward, n0, a.n, dn);
-        }
-        Pk<1> c[T::SLOTS];
-        encode<T, 1>(s, c);
-#pragma unroll
-        for (int p = 0; p < T::SLOTS; ++p) *reinterpret_cast<uint32_t *>(lds_code + p * TP + lo) = c[p].d[0];
-    }
-    __syncthreads();
-    const int64_t left = a.n - tile0;
-    const int ncubes = left < TILE ? (int)left : TILE;
-    dense_write<T, E>(lds_code, TP, dense + tile0 * (T::R * T::C), ncubes, threadIdx.x, kDenseBlock);
-    __syncthreads();                                               // the code tile is reused by the next iteration
+        if (lo < TILE && tile0 + lo < a.n) dense_produce<T, MOVE, STORE>(a, tile0, lo, lds_code, TP);
+        __syncthreads();
+        const int64_t left = a.n - tile0;
+        const int ncubes = left < TILE ? (int)left : TILE;
+        dense_write<T, E>(lds_code, TP, dense + tile0 * (T::R * T::C), ncubes, threadIdx.x, kDenseBlock);
+        __syncthreads();                                               // the code tile is reused by the next iteration
     }
 }
 
@@ -263,6 +266,39 @@ __global__ void __launch_bounds__(kDenseBlock) k_code_to_dense(const uint8_t *co
     const int ncubes = left < TILE ? (int)left : TILE;
     dense_write<T, E>(lds_code, TP, dense + tile0 * (T::R * T::C), ncubes, threadIdx.x, kDenseBlock);
     __syncthreads();
+    }
+}
+
+// WIDE form of the code -> dense writer (3x3x3, batches from 2^17 cubes): 960-thread workgroups (15 waves; 960 = 8 * 120
+// covers whole cubes for every element size), about 112 of them, each sweeping ONE contiguous range of 256-cube tiles, so the
+// chip writes ~112 long sequential streams of 15-KiB bursts instead of 2048-4096 interleaved 4-KiB ones.  Measured at 2^20
+// cubes in the same process on the same buffers (profiles/r03_ab.json): bf16 0.68-0.72 -> 0.77-0.91 of the 8 TB/s peak, f32
+// 0.66-0.83 -> 0.71-0.92, u8 0.67-0.74 -> 0.77-0.85 (the spread is between GPU boxes); at least level with the 256-thread form
+// for every batch size tried (2^17 .. 2^22, powers of two and not).  Group counts from 64 to 512 were swept: ~112 is the best
+// or within 2 % of it for all three element sizes; 64 groups are too few waves.
+constexpr int kWideBlock = 960, kWideGroups = 112, kWideTile = 256;
+
+template <class T, class E>
+__global__ void __launch_bounds__(kWideBlock) k_code_to_dense_wide(const uint8_t *code, int64_t n, int64_t code_pitch, int shift, E *dense,
+                                                                   int64_t tiles_per_group) {
+    constexpr int TILE = kWideTile, TP = TILE + 4;
+    __shared__ __attribute__((aligned(16))) uint8_t lds_code[2][T::SLOTS * TP];
+    const uint32_t lo = threadIdx.x * 4;
+    const int64_t first = (int64_t)blockIdx.x * tiles_per_group * TILE;
+    int64_t last = first + tiles_per_group * TILE;
+    if (last > n) last = n;
+    int buf = 0;
+    for (int64_t tile0 = first; tile0 < last; tile0 += TILE, buf ^= 1) {
+        if (lo < TILE && tile0 + lo < n) {
+            const __amdgpu_buffer_rsrc_t r = make_srd(code + tile_off(tile0, code_pitch, shift, T::SLOTS));
+            const uint32_t rs = (uint32_t)code_pitch;
+#pragma unroll
+            for (int p = 0; p < T::SLOTS; ++p) *reinterpret_cast<uint32_t *>(lds_code[buf] + p * TP + lo) = bld<1, kAuxCached>(r, lo, p * rs).d[0];
+        }
+        __syncthreads();                                            // double-buffered tile: one barrier per tile is enough
+        const int64_t left = n - tile0;
+        const int ncubes = left < TILE ? (int)left : TILE;
+        dense_write_333<T, E, kWideBlock>(lds_code[buf], TP, dense + tile0 * (T::R * T::C), ncubes, threadIdx.x);
     }
 }
 
@@ -352,7 +388,7 @@ __global__ void __launch_bounds__(kWave) k_expand(ExpandArgs a) {
                      a.child_code ? a.child_code + tile_off(g0, a.pitch_out, a.sh_out, T::SLOTS) : nullptr, (uint32_t)a.pitch_out, a.tiles_out, true};
     FamilyCodes<T, V> fam;
     ChildFlags<T, V> cf;
-    if constexpr (CODE) family_codes<T, V>(s, fam);
+    if constexpr (CODE) family_codes<T, V, false>(s, fam);
     emit_children<T, V, CODE, false>(s, fam, cf, part, a.parts, o, lo);
 }
 
@@ -425,7 +461,7 @@ __global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
         if (d < d_lo) continue;                               // another segment's depth: replayed, nothing emitted (wave-uniform)
         FamilyCodes<T, V> fam;
         ChildFlags<T, V> cf;
-        if constexpr (CODE) family_codes<T, V>(s, fam);
+        if constexpr (CODE) family_codes<T, V, true>(s, fam);
         // a child can only be solved when its parent is a power of one face turn away from solved, i.e. when every sticker outside
         // that face's ring is home (not_ring == 0).  After a few random moves no walk of the wave is: skip the 12 ring tests.
         bool flags_live = false;
@@ -879,12 +915,33 @@ int dispatch_step(const StepArgs &a, hipStream_t st, int variant) {
     return p.v == 2 ? launch_step<T, 2, MOVE, STORE, CODE>(a, st, p.pol) : launch_step<T, 1, MOVE, STORE, CODE>(a, st, p.pol);
 }
 
+// Dense writer form.  100000s digit of `variant`: 1 -> 64-cube tiles, 2 -> 256-cube tiles (256-thread workgroups), 3 -> the wide
+// form (3x3x3 only).  Default: wide from 2^17 cubes (3x3x3), 256-cube tiles for 2x2x2 batches of that size, else 64-cube tiles
+// (small batches -- MCTS leaves -- stay spread over the chip: 4096 cubes are 64 workgroups).
 // Measured at 1M cubes (tools/microbench.py densetile): 256-cube tiles 5.4 TB/s (f32) / 6.3 TB/s (u8) against
-// 4.9 / 5.4 with 1024-cube tiles -- shorter private write streams per workgroup.
-inline int dense_tile(int64_t n, int variant) {
+// 4.9 / 5.4 with 1024-cube tiles -- shorter private write streams per workgroup; the wide form: see k_code_to_dense_wide.
+enum DenseForm { kDense64 = 64, kDense256 = 256, kDenseWide = 960 };
+template <class T>
+inline DenseForm dense_form(int64_t n, int variant, bool fused) {
+    const bool wide_ok = T::SIZE == 3 && !fused;   // the wide form exists for code -> dense only: a FUSED wide kernel (every wave
+    //   produces a tile, then all sweep 15 tiles) was built and measured in round 3 and lost to the 256-thread form for every
+    //   format and group count (bf16 0.62-0.74 against 0.74-0.76: its ~110 workgroups funnel the state traffic and stall the
+    //   dense stream while they produce; profiles/r03_ab.json "dense_wide_groups")
     const int forced = (variant / 100000) % 10;
-    if (forced) return forced == 1 ? 64 : 256;
-    return n >= ((int64_t)1 << 17) ? 256 : 64;
+    if (forced == 1) return kDense64;
+    if (forced == 2) return kDense256;
+    if (forced == 3) return wide_ok ? kDenseWide : kDense256;
+    if (n < ((int64_t)1 << 17)) return kDense64;
+    return wide_ok ? kDenseWide : kDense256;
+}
+struct WideGrid { int64_t groups, per; };
+// `variant` thousands field (2 digits, otherwise the expansion's parts): wanted workgroups / 16, for tuning sweeps
+inline WideGrid wide_grid(int64_t n, int variant) {
+    const int64_t tiles = (n + kWideTile - 1) / kWideTile;
+    const int f = (variant / 1000) % 100;
+    const int64_t want = f ? f * 16 : kWideGroups;
+    const int64_t per = (tiles + want - 1) / want;
+    return {(tiles + per - 1) / per, per};
 }
 
 // The dense kernels loop over tiles (grid-stride).  f32 rows (1920 B per cube) run 5 % faster at 1M cubes when the grid is
@@ -908,9 +965,9 @@ int launch_dense_t(const StepArgs &a, void *onehot, int fmt, hipStream_t st) {
 
 template <class T, bool MOVE, bool STORE>
 int launch_dense(const StepArgs &a, void *onehot, int fmt, hipStream_t st, int variant) {
-    switch (dense_tile(a.n, variant)) {
-        case 256: return launch_dense_t<T, MOVE, STORE, 256>(a, onehot, fmt, st);
-        default: return launch_dense_t<T, MOVE, STORE, 64>(a, onehot, fmt, st);
+    switch (dense_form<T>(a.n, variant, true)) {
+        case kDense64: return launch_dense_t<T, MOVE, STORE, 64>(a, onehot, fmt, st);
+        default: return launch_dense_t<T, MOVE, STORE, 256>(a, onehot, fmt, st);
     }
 }
 
@@ -926,6 +983,23 @@ int launch_code_to_dense(const uint8_t *code, int64_t n, int64_t code_pitch, int
     else hipLaunchKernelGGL((k_code_to_dense<T, float, TILE>), g, b, 0, st, code, n, code_pitch, sh, static_cast<float *>(onehot));
     RC_HIP(hipGetLastError());
     return RC_OK;
+}
+
+template <class T>
+int launch_code_to_dense_wide(const uint8_t *code, int64_t n, int64_t code_pitch, int sh, void *onehot, int fmt, hipStream_t st, int variant) {
+    if constexpr (T::SIZE == 3) {
+        const WideGrid w = wide_grid(n, variant);
+        RC_GRID(w.groups);
+        const dim3 g((unsigned)w.groups), b(kWideBlock);
+        if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_code_to_dense_wide<T, uint8_t>), g, b, 0, st, code, n, code_pitch, sh, static_cast<uint8_t *>(onehot), w.per);
+        else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_code_to_dense_wide<T, uint16_t>), g, b, 0, st, code, n, code_pitch, sh, static_cast<uint16_t *>(onehot), w.per);
+        else if (fmt == RC_FMT_BF16) hipLaunchKernelGGL((k_code_to_dense_wide<T, Bf16>), g, b, 0, st, code, n, code_pitch, sh, static_cast<Bf16 *>(onehot), w.per);
+        else hipLaunchKernelGGL((k_code_to_dense_wide<T, float>), g, b, 0, st, code, n, code_pitch, sh, static_cast<float *>(onehot), w.per);
+        RC_HIP(hipGetLastError());
+        return RC_OK;
+    } else {
+        return launch_code_to_dense<T, 256>(code, n, code_pitch, sh, onehot, fmt, st);
+    }
 }
 
 int check_fmt(void *onehot, int fmt, int64_t code_pitch, int64_t n, int *sh_code) {
@@ -1169,7 +1243,7 @@ int rc_encode(const uint8_t *stp, int64_t n, int64_t pitch, int cube_size, void 
     return step_common(stp, nullptr, nullptr, n, pitch, 0, cube_size, nullptr, nullptr, onehot, fmt, code_pitch, stream, false, false, 0);
 }
 
-int rc_onehot_from_code(const uint8_t *code, int64_t n, int64_t code_pitch, int cube_size, void *onehot, int fmt, void *stream) {
+int rc_onehot_from_code_ex(const uint8_t *code, int64_t n, int64_t code_pitch, int cube_size, void *onehot, int fmt, void *stream, int variant) {
     RC_NEED_INIT();
     const int sh = tile_shift(code_pitch, n, 20);
     if (!code || !aligned16(code) || n < 0 || sh < 0) return fail(RC_EINVAL, "bad code buffer / pitch%s");
@@ -1177,11 +1251,16 @@ int rc_onehot_from_code(const uint8_t *code, int64_t n, int64_t code_pitch, int 
     if (n == 0) return RC_OK;
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
-        switch (dense_tile(n, 0)) {
-            case 256: return launch_code_to_dense<T, 256>(code, n, code_pitch, sh, onehot, fmt, S(stream));
+        switch (dense_form<T>(n, variant, false)) {
+            case kDenseWide: return launch_code_to_dense_wide<T>(code, n, code_pitch, sh, onehot, fmt, S(stream), variant);
+            case kDense256: return launch_code_to_dense<T, 256>(code, n, code_pitch, sh, onehot, fmt, S(stream));
             default: return launch_code_to_dense<T, 64>(code, n, code_pitch, sh, onehot, fmt, S(stream));
         }
     });
+}
+
+int rc_onehot_from_code(const uint8_t *code, int64_t n, int64_t code_pitch, int cube_size, void *onehot, int fmt, void *stream) {
+    return rc_onehot_from_code_ex(code, n, code_pitch, cube_size, onehot, fmt, stream, 0);
 }
 
 int rc_expand_children_ex(const uint8_t *in, int64_t n, int64_t pitch_in, int cube_size, uint8_t *children, uint8_t *child_solved,
@@ -1356,9 +1435,9 @@ int rc_describe_dispatch(int op, int cube_size, int64_t n, int depth, unsigned o
         if (op == RC_OP_STEP) {
             if (fmt >= RC_FMT_U8 && fmt <= RC_FMT_BF16) {
                 static const char *const names[] = {"", "", "u8", "f16", "f32", "bf16"};
-                const int tile = dense_tile(n, variant);
+                const int form = (int)dense_form<T>(n, variant, true);
                 snprintf(buf, buflen, "k_step_dense<%s,%s,%s,TILE=%d> grid=%lld block=%d", cube, names[fmt], states ? "move,store" : "encode",
-                         tile, (long long)dense_grid((n + tile - 1) / tile, fmt), kDenseBlock);
+                         form, (long long)dense_grid((n + form - 1) / form, fmt), kDenseBlock);
                 return RC_OK;
             }
             const bool with_code = code || fmt == RC_FMT_CODE;
@@ -1370,8 +1449,13 @@ int rc_describe_dispatch(int op, int cube_size, int64_t n, int depth, unsigned o
         if (op == RC_OP_CODE_TO_DENSE) {
             static const char *const names[] = {"", "", "u8", "f16", "f32", "bf16"};
             if (fmt < RC_FMT_U8 || fmt > RC_FMT_BF16) return fail(RC_EINVAL, "rc_describe_dispatch: dense fmt required%s");
-            const int tile = dense_tile(n, 0);
-            snprintf(buf, buflen, "k_code_to_dense<%s,%s,TILE=%d> grid=%lld block=%d", cube, names[fmt], tile, (long long)dense_grid((n + tile - 1) / tile, fmt), kDenseBlock);
+            const DenseForm form = dense_form<T>(n, variant, false);
+            if (form == kDenseWide) {
+                const WideGrid w = wide_grid(n, variant);
+                snprintf(buf, buflen, "k_code_to_dense_wide<%s,%s> tiles_per_group=%lld grid=%lld block=%d", cube, names[fmt], (long long)w.per, (long long)w.groups, kWideBlock);
+            } else {
+                snprintf(buf, buflen, "k_code_to_dense<%s,%s,TILE=%d> grid=%lld block=%d", cube, names[fmt], (int)form, (long long)dense_grid((n + (int)form - 1) / (int)form, fmt), kDenseBlock);
+            }
             return RC_OK;
         }
         if (op == RC_OP_EXPAND) {

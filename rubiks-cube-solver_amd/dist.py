@@ -13,10 +13,15 @@ import os
 # runtime initialises, so it is set at IMPORT time (import this module before the first GPU call of the process; the
 # launcher normally exports it already) -- setting it inside init() would come too late in a process that already
 # touched the GPU.
+_IPC_WAS_SET = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"    # before the setdefault below: what the HIP runtime may already have read
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
+
+# a process that initialised the GPU before importing this module and without the variable exported started its HIP runtime in
+# legacy IPC mode: setting the variable now does not change that
+_TOO_LATE = (not _IPC_WAS_SET) and torch.cuda.is_initialized()
 
 
 def world():
@@ -41,9 +46,9 @@ def init(backend=None, device=None):
     """Initialise the default process group when launched with WORLD_SIZE > 1 (reporting only)."""
     rank, ws, local = world()
     if ws > 1 and not dist.is_initialized():
-        if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0" and torch.cuda.is_initialized():
-            raise RuntimeError("HSA_ENABLE_IPC_MODE_LEGACY=0 must be exported before the process first touches the GPU "
-                               "(RCCL needs dmabuf IPC here)")
+        if _TOO_LATE and (backend or "nccl") == "nccl":
+            raise RuntimeError("HSA_ENABLE_IPC_MODE_LEGACY=0 must be exported (or this module imported) before the process first "
+                               "touches the GPU: RCCL needs dmabuf IPC here")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}

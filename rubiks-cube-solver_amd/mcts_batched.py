@@ -162,12 +162,15 @@ class BatchedMCTS:
     """R roots searched in lockstep on one GPU (config 5: 4096 roots x 12 children per step)."""
 
     def __init__(self, model, root_stickers, n_roots, cube_size=3, cpuct=1.0, virtual_loss=150.0, value_min=-10.0,
-                 device="cuda", overlap=False, rngs=None, graph=False, native=True):
+                 device="cuda", rngs=None, graph=False, native=True):
         """rngs: optional list of `random.Random` (one per root) for the untried-node draws (mcts.py:69-70); with
         root r's generator seeded like a stand-alone run, root r's search is that run (default: the global `random`).
-        overlap: run the expansion on a side stream next to the net forward.  Off by default: at 4096 leaves the
-        expansion takes 9 us and the cross-stream dependencies cost more than that (DESIGN.md "Config 5").
-        graph: capture the per-simulation kernel sequence as a hipGraph and replay it (launch-bound loop)."""
+        With native=True the generators' states are COPIED into the C++ trees and advanced there: call sync_rngs() before
+        using the Python objects again (native=False consumes them in place).
+        graph: capture the per-simulation kernel sequence as a hipGraph and replay it (launch-bound loop).
+        Everything runs on ONE stream: expansion on a side stream next to the net forward was measured and loses at this
+        size (8-9 us of expansion against the cost of two cross-stream dependencies; tools/bench_cfg5.py still reports the
+        interleaved shape for BASELINE config 5, DESIGN.md "Config 5")."""
         self.model, self.cube_size, self.n = model, cube_size, int(n_roots)
         self.c, self.vl, self.vmin = cpuct, virtual_loss, value_min
         self.dev = torch.device(device)
@@ -192,7 +195,6 @@ class BatchedMCTS:
         self._leaf_aos = torch.empty((self.n, SL), dtype=torch.uint8, device=self.dev)
         self._child_aos = torch.empty((self.n, self.A, SL), dtype=torch.uint8, device=self.dev)
         self._solved_aos = torch.empty((self.n, self.A), dtype=torch.uint8, device=self.dev)
-        self.side = torch.cuda.Stream(self.dev) if overlap else None
         self.graph, self._graphs, self._paths, self._host = bool(graph), {}, None, None
 
     def __getattr__(self, name):
@@ -223,18 +225,11 @@ class BatchedMCTS:
         if depth:
             ops.scramble(self.work, n, cs, depth, actions_in=self._paths[:depth])
         pitch = self.work.shape[-1]
-        if self.side is not None:
-            self.side.wait_stream(torch.cuda.current_stream(self.dev))
-            with torch.cuda.stream(self.side):
-                ops.expand_children(self.work, n, cs, None, self.ex["child_solved"], self.ex["child_code"], pitch=pitch)
-        else:
-            ops.expand_children(self.work, n, cs, None, self.ex["child_solved"], self.ex["child_code"], pitch=pitch)
+        ops.expand_children(self.work, n, cs, None, self.ex["child_solved"], self.ex["child_code"], pitch=pitch)
         ops.encode(self.work, n, cs, self.code, _lib.FMT_CODE)
         ops.onehot_from_code(self.code, n, cs, self.onehot)
         value, logits = self.model(self.onehot)
         policy = torch.softmax(logits, dim=-1)          # model.py:89
-        if self.side is not None:
-            torch.cuda.current_stream(self.dev).wait_stream(self.side)
         self._leaf_aos.copy_(ops.to_aos(self.code, n))
         cc = self.ex["child_code"]                                              # [A, tiles, SLOTS, pitch]
         self._child_aos.copy_(cc.permute(1, 3, 0, 2).reshape(-1, self.A, cc.shape[2])[:n])
@@ -282,6 +277,12 @@ class BatchedMCTS:
         code_h, cc_h, cs_h, v_h, p_h = (h.numpy() for h in self._host)
         # copies: the pinned buffers are overwritten by the next simulation (the Python tree keeps policy rows)
         return code_h.copy(), cc_h.copy(), cs_h.astype(bool), v_h.reshape(-1).copy(), p_h.copy()
+
+    def sync_rngs(self):
+        """Write the per-root generators' current states back into the `random.Random` objects passed as `rngs` (native trees
+        advance private copies; the Python trees consume the objects in place, nothing to do)."""
+        if self.native is not None:
+            self.native.sync_rngs()
 
     def simulate(self):
         """One simulation for every unsolved root.  Returns the number of roots solved so far."""

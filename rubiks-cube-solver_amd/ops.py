@@ -201,13 +201,13 @@ def encode(st, n, cube_size, onehot, fmt):
     check(lib().rc_encode(ptr(st), n, pitch, cube_size, ptr(oh), fmt, cp, stream_ptr(st.device)))
 
 
-def onehot_from_code(code, n, cube_size, onehot):
+def onehot_from_code(code, n, cube_size, onehot, variant=0):
     _size(cube_size)
     cp = _tiled(code, N_SLOTS[cube_size], n, "onehot_from_code")
     fmt = _lib.fmt_of(onehot.dtype)
     _onehot_args(onehot, fmt, n, cube_size, "onehot_from_code")
     _lib.init(code.device)
-    check(lib().rc_onehot_from_code(ptr(code), n, cp, cube_size, ptr(onehot), fmt, stream_ptr(code.device)))
+    check(lib().rc_onehot_from_code_ex(ptr(code), n, cp, cube_size, ptr(onehot), fmt, stream_ptr(code.device), variant))
 
 
 def _tiles_of(n, pitch):

@@ -146,17 +146,31 @@ class TensorReplayBuffer(Dataset):
     def batches(self, batch_size, shuffle=True, dtype=torch.float32):
         """The mini-batches DataLoader(self, batch_size, shuffle) would yield (update_params, utils.py:296-303), without a
         Python call per sample: (state [B,R,C] `dtype`, target_value, target_policy, scramble_count, memory_idx).  The order comes
-        from torch's own RandomSampler, so the same torch seed visits the samples in the DataLoader's order."""
-        from torch.utils.data import BatchSampler, RandomSampler, SequentialSampler
+        from a DataLoader over the bare indices, so the same torch seed visits the samples in exactly the DataLoader's order."""
+        from torch.utils.data import DataLoader
 
-        sampler = RandomSampler(self) if shuffle else SequentialSampler(self)
         mem = torch.from_numpy(np.asarray(self.prioritized_idx, dtype=np.int64))
         phys_all = torch.from_numpy(self._phys(np.asarray(self.prioritized_idx, dtype=np.int64))).to(self.device)
-        for chunk in BatchSampler(sampler, batch_size, drop_last=False):
-            i = torch.as_tensor(chunk, dtype=torch.int64)
-            p = phys_all[i.to(self.device)]
-            yield (self._dense[i.to(self.device)].to(dtype), self.target_value[p], self.target_policy[p], self.scramble_count[p],
-                   mem[i].to(self.device))
+        # the DataLoader itself walks an index-only view of this buffer: same sampler, same draws from torch's generator
+        order = DataLoader(_Indices(len(self)), batch_size=batch_size, shuffle=shuffle, collate_fn=lambda b: torch.as_tensor(b, dtype=torch.int64))
+        for i in order:
+            d = i.to(self.device)
+            p = phys_all[d]
+            yield (self._dense[d].to(dtype), self.target_value[p], self.target_policy[p], self.scramble_count[p], mem[i].to(self.device))
+
+
+class _Indices(Dataset):
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return int(i)
+
+    def __getitems__(self, idx):
+        return list(idx)
 
 
 def _code_of_dense(state, cube_size):

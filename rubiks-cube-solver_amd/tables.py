@@ -233,6 +233,62 @@ def get_tables(cube_size: int) -> CubeTables:
     )
 
 
+# ------------------------------------------------------ pair-indexed code tables (device look-ups)
+# sigma id of a reading order (j0, j1, j2) of a corner slot's three stickers, as rc_device.h numbers them
+SIGMAS = [(0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0)]
+
+
+@functools.lru_cache(maxsize=None)
+def pair_tables(cube_size: int):
+    """Code look-ups indexed by TWO colours instead of the hash (the kernels' v_perm tables have 8 entries: a row per second
+    colour, the first colour selects inside the row).
+
+    edge_pair[c1][c0] = edge_code[c0 + 10*c1]: the hash is injective in (c0, c1), so this is exact for ANY colouring.
+    Corners: on states reachable from the solved cube the first two colours of a slot read in a fixed order determine the
+    third (a cubie is a fixed colour triple and a slot reads it in a fixed handedness), so
+    corner_pair[table][c1][c0] = corner_code[c0 + 2*c1 + 10*c2(c0, c1)] -- including the reference's missing rows (zeros).
+    The handedness depends on the slot and on the reading order: corner_table[q][sigma] names the table of slot q read in
+    order SIGMAS[sigma].  Built by enumeration: random walks from the solved cube visit all 24 (21) triples of every slot; the
+    generator asserts that (c0, c1) determines c2 and that walks of twice the length find nothing new.
+    Returns (edge_pair uint8 [6][8], corner_pair uint8 [K][6][8], corner_table uint8 [NC][6])."""
+    t = get_tables(cube_size)
+    rng = np.random.default_rng(20260 + cube_size)
+    A = t.n_actions
+    seen = [set() for _ in t.corner_defs]
+    st = np.tile(t.solved, (4096, 1))
+    for step in range(60):
+        acts = rng.integers(0, A, len(st))
+        st = np.stack([s[t.perm[a]] for s, a in zip(st, acts)]) if step == 0 else st[np.arange(len(st))[:, None], t.perm[acts]]
+        for q, d in enumerate(t.corner_defs):
+            seen[q].update(map(tuple, st[:, d].tolist()))
+        if step == 29:
+            counts = [len(x) for x in seen]
+    assert counts == [len(x) for x in seen] and set(counts) == {3 * (8 if cube_size == 3 else 7)}, counts
+    tables, index = [], np.zeros((len(t.corner_defs), 6), np.uint8)
+    for q in range(len(t.corner_defs)):
+        for sid, sg in enumerate(SIGMAS):
+            tab = np.zeros((6, 8), np.uint8)
+            third = {}
+            for tri in seen[q]:
+                c0, c1, c2 = tri[sg[0]], tri[sg[1]], tri[sg[2]]
+                assert third.setdefault((c0, c1), c2) == c2          # two colours determine the third
+                h = c0 + 2 * c1 + 10 * c2
+                tab[c1][c0] = t.corner_code[h] if h < LUT_PAD else 0
+            for k, have in enumerate(tables):
+                if (have == tab).all():
+                    index[q, sid] = k
+                    break
+            else:
+                index[q, sid] = len(tables)
+                tables.append(tab)
+    epair = np.zeros((6, 8), np.uint8)
+    if len(t.edge_defs):
+        for c1 in range(6):
+            for c0 in range(6):
+                epair[c1][c0] = t.edge_code[c0 + 10 * c1]
+    return epair, np.stack(tables), index
+
+
 def get_env_config(cube_size: int = 3):
     """([rows, cols] of the one-hot state, number of actions) -- utils.py:162-186."""
     if cube_size not in (2, 3):

@@ -11,7 +11,7 @@ Nothing from the reference is copied: the fixtures hold inputs (action sequences
 seeds, stub-model weights) and the outputs the reference computed for them.
 
     python -B tests/golden/make_golden.py            # everything
-    python -B tests/golden/make_golden.py mcts       # only the named groups (tables walks reset adi expand encode mcts rollout adi_deepcube replay)
+    python -B tests/golden/make_golden.py mcts       # only the named groups (tables walks reset adi expand encode mcts rollout adi_deepcube replay mcts_guided)
 
 Fixtures written (all small, np.savez_compressed):
   tables_333.npz   G1  tables as data (perm table, piece defs, hash weights, LUTs)
@@ -28,6 +28,8 @@ Fixtures written (all small, np.savez_compressed):
   adi_deepcube_333.npz G10 get_random_samples with the reference's DeepCube as the model
   replay_333.npz   G11 the reference's ReplayBuffer (utils.py:203-270) fed by get_random_samples (G5's stub model): deque
                    eviction, prioritised indices under seeded legacy draws, __getitem__ tuples, update(), DataLoader order
+  mcts_guided_333.npz G12 the reference's MCTS with a guiding stub (value = rows at home): depth 3-5 scrambles that ARE
+                   solved; simulations, action lists and the statistics of every node on the returned path
   mcts_333.npz     G8  the reference's MCTS (mcts.py) driven by a deterministic stub model and a
                    seeded `random`: simulations needed, returned action lists, root statistics;
                    plus reset(seed, 1000) end states for seeds 0..19 (test.py:166,279 style)
@@ -95,7 +97,9 @@ def main():
         golden_adi_deepcube(torch, env)
     if want("replay"):
         golden_replay(torch, env)
-    if groups and not (groups - {"mcts", "rollout", "adi_deepcube", "replay"}):
+    if want("mcts_guided"):
+        golden_mcts_guided(torch, cube_env, env)
+    if groups and not (groups - {"mcts", "rollout", "adi_deepcube", "replay", "mcts_guided"}):
         return
     np.savez_compressed(
         os.path.join(HERE, "tables_333.npz"),
@@ -387,6 +391,86 @@ def golden_replay(torch, env):
     np.savez_compressed(os.path.join(HERE, "replay_333.npz"), buf_size=np.int64(buf_size), sample_size=np.int64(sample_size),
                         mem_cols=mem_cols, mem_err=mem_err, upd_idx=upd_idx, upd_err=upd_err, **out)
     print("replay:", len(out["idx1"]), "prioritised of", buf_size, "dtypes", list(out["item_dtypes"]))
+
+
+def golden_mcts_guided(torch, cube_env, env):
+    """G12: the reference's MCTS (mcts.py:36-154) with a GUIDING stub so that deep searches succeed and the found-solution path
+    is exercised: a table of every state within 4 moves of the solved cube (breadth-first with the reference env itself:
+    one-hot columns -> distance d and the move that leads back towards solved).  predict(state) = (value -d, policy softmax
+    with logit 2 on that move) for tabled states, (-9, uniform) otherwise.  For seeds 0..11 x k in {3, 4, 5}: simulations
+    used, the returned action list, and the statistics (visits, values, virtual losses) of EVERY node on the returned path."""
+    import random
+
+    import mcts as ref_mcts
+
+    env.init_state()
+    start = env.sim_cube.copy()
+    table = {tuple(cols_of(env.cube)): (0, 0)}
+    frontier = [start]
+    for depth in range(1, 5):
+        nxt = []
+        for st in frontier:
+            for a in range(12):
+                env.sim_cube = st.copy()
+                oh, _, _, _ = env.step(a)
+                key = tuple(cols_of(oh))
+                if key not in table:
+                    table[key] = (depth, a ^ 1)                       # X' undoes X: actions come in (2f, 2f+1) pairs
+                    nxt.append(env.sim_cube.copy())
+        frontier = nxt
+    t_cols = np.array(list(table.keys()), np.uint8)
+    t_depth = np.array([v[0] for v in table.values()], np.uint8)
+    t_back = np.array([v[1] for v in table.values()], np.uint8)
+
+    class Stub:
+        def predict(self, x):
+            hit = table.get(tuple(cols_of(np.asarray(x))))
+            logits = np.zeros(12, np.float32)
+            value = np.float32(-9.0)
+            if hit is not None:
+                value = np.float32(-float(hit[0]))
+                logits[hit[1]] = 2.0
+            e = np.exp(logits - logits.max())
+            return np.array([value], np.float32), (e / e.sum()).astype(np.float32)
+
+    cfg = {"mcts": {"virtual_loss_const": 150, "cpuct": 1.0, "value_min": -10.0, "numMCTSSim": 50}, "test": {"cube_size": 3}}
+    cases = [(s, k) for k in (3, 4, 5) for s in range(12)]
+    LMAX = 24
+    sims, sol, p_vis, p_val, p_vl, p_len = [], [], [], [], [], []
+    for seed, k in cases:
+        state = env.reset(seed=seed, scramble_count=k)
+        random.seed(5000 + 13 * seed + k)
+        tree = ref_mcts.MCTS(Stub(), cfg)
+        found, used = None, 0
+        for i in range(60):
+            used = i + 1
+            found = tree.train(state, env)
+            if found is not None:
+                break
+        sims.append(used)
+        a = np.full(LMAX, 255, np.uint8)
+        vis, val, vl = np.zeros((LMAX, 12), np.int64), np.zeros((LMAX, 12), np.float64), np.zeros((LMAX, 12), np.float64)
+        n_nodes = 0
+        if found is not None:
+            assert len(found) <= LMAX
+            a[:len(found)] = found
+            key = np.array2string(state)
+            for t in range(len(found)):                               # every node from the root to the expanded leaf
+                node = tree.children_and_data[key]
+                vis[t] = node[tree.n_of_v_i]
+                val[t] = [float(np.asarray(v).reshape(-1)[0]) for v in node[tree.s_i]]
+                vl[t] = node[tree.v_l_i]
+                key = node[tree.ch_i][found[t]]
+                n_nodes += 1
+        sol.append(a); p_vis.append(vis); p_val.append(val); p_vl.append(vl); p_len.append(n_nodes)
+    np.savez_compressed(
+        os.path.join(HERE, "mcts_guided_333.npz"),
+        table_cols=t_cols, table_depth=t_depth, table_back=t_back,
+        seeds=np.array([c[0] for c in cases]), ks=np.array([c[1] for c in cases]),
+        random_seed=np.array([5000 + 13 * s + k for s, k in cases]), sims=np.array(sims), solution=np.stack(sol),
+        path_nodes=np.array(p_len), path_visits=np.stack(p_vis), path_values=np.stack(p_val), path_vloss=np.stack(p_vl))
+    found_by_k = {k: int(sum(1 for (s_, k_), n in zip(cases, p_len) if k_ == k and n)) for k in (3, 4, 5)}
+    print("mcts_guided: table", len(table), "found per depth", found_by_k, "sims", sims, "path lengths", p_len)
 
 
 def golden_mcts(torch, cube_env, env):

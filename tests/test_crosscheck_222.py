@@ -82,11 +82,15 @@ def test_checkpoint_policy_solves_our_222_cubes():
     assert rates[1] >= 0.9 and rates[2] >= 0.9 and rates[4] >= 0.8
 
 
+def _fixture():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "crosscheck_222.npz"))
+
+
 def test_fixture_matches_live_checkpoint_run():
     """tests/golden/crosscheck_222.npz (actions and outcomes of the run above, no weights) is what the checkpoint does
     on the restated env today: regenerate a slice and compare."""
     from oracle.oracle_np import OracleCubeEnv
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "crosscheck_222.npz"))
+    g = _fixture()
     sd = read_state_dict_statically(CKPT)
     env = OracleCubeEnv(None, 2)
     for i in range(0, len(g["seeds"]), 7):
@@ -96,3 +100,20 @@ def test_fixture_matches_live_checkpoint_run():
             assert a == g["actions"][i, t]
             state, _, d, _ = env.step(a)
             assert (np.argmax(state, 1) == g["cols"][i, t]).all() and d == g["done"][i, t]
+
+
+def test_negative_controls_regenerate():
+    """The control conventions of the fixture are re-run here on a slice (greedy, depths 2 and 6, 20 seeds): the live rates
+    equal what the fixture recorded for those seeds' population within sampling, and every control stays far below the
+    shipped convention."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_crosscheck_222 as mk
+    sd = read_state_dict_statically(CKPT)
+    live = {}
+    for conv in mk.CONVENTIONS:
+        env = mk.ConventionEnv(conv)
+        live[conv] = [np.mean([mk.greedy(sd, env, seed, k)[3] > 0 for seed in range(20)]) for k in (2, 6)]
+    assert live["shipped"] == [1.0, 1.0]
+    for conv in mk.CONVENTIONS[1:]:
+        assert live[conv][0] <= 0.5 and live[conv][1] <= 0.15, (conv, live[conv])

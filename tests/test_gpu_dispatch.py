@@ -262,6 +262,58 @@ def test_adi_codes_default_dispatch_100k(ops, L, oracle):
     assert L.read_status() == 0
 
 
+@pytest.mark.parametrize("n", [1, 255, 1000, 3841, 70001, (1 << 17) + 77, 300_001])
+def test_dense_writer_forms(ops, L, oracle, n):
+    """Every form of the dense one-hot writers (64-cube tiles, 256-cube tiles, the wide 960-thread code -> dense form and the
+    default dispatch) x every element type, fused with the move (ping-pong and in place), encode-only and code -> dense, ragged sizes
+    around the tile (256), round (15 tiles = 3840 cubes) and group boundaries: the one-hot's arg-max is the oracle's code,
+    every row holds exactly one 1, states / done / reward equal the oracle's (py333.py:220-246, cube_env.py:71-111)."""
+    cs = 3
+    states = walk_states(oracle, cs, n, 12, seed=n % 1000)
+    acts = np.random.default_rng(n).integers(0, 12, n, dtype=np.uint8)
+    k = min(n, 64)
+    states[:k] = oracle.step(cs, oracle.solved(cs, k), acts[:k] ^ 1)[0]                  # these become solved
+    exp_st, exp_code, exp_done, exp_rew = oracle.step(cs, states, acts, threads=8)
+    src = ops.from_aos(states, "cuda")
+    a_d = torch.from_numpy(acts).cuda()
+    exp_code_t = torch.from_numpy(exp_code).cuda()
+    code_buf = ops.alloc_code(n, cs, "cuda")
+    ops.encode(src, n, cs, code_buf, L.FMT_CODE)
+    src_code = ops.to_aos(code_buf, n)
+    fmts = ((L.FMT_U8, torch.uint8), (L.FMT_F16, torch.float16), (L.FMT_BF16, torch.bfloat16), (L.FMT_F32, torch.float32))
+    for form in (0, 100000, 200000, 300000):
+        if n > 100000 and form == 100000:
+            continue                                                                     # 64-cube tiles at 300k cubes: covered at 70001
+        for fmt, dt in fmts:
+            tag = (n, form, str(dt))
+            oh = torch.full((n, 20, 24), 3, dtype=dt, device="cuda")
+            dst = torch.zeros_like(src)
+            rew = torch.zeros(n, dtype=torch.float32, device="cuda")
+            done = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
+            ops.apply_moves(src, dst, a_d, n, cs, rew, done, oh, fmt, variant=form)
+            assert torch.equal(oh.float().argmax(-1).to(torch.uint8), exp_code_t), tag
+            assert float(oh.float().sum()) == 20.0 * n and float(oh.float().max()) == 1.0, tag
+            assert (ops.to_aos(dst, n).cpu().numpy() == exp_st).all(), tag
+            assert (done.cpu().numpy() == exp_done).all() and (rew.cpu().numpy() == exp_rew).all(), tag
+            # in place
+            work = src.clone()
+            oh.fill_(3)
+            ops.apply_moves(work, work, a_d, n, cs, None, done, oh, fmt, variant=form)
+            assert torch.equal(work, dst) and torch.equal(oh.float().argmax(-1).to(torch.uint8), exp_code_t), tag
+            # code -> dense
+            oh.fill_(3)
+            ops.onehot_from_code(code_buf, n, cs, oh, variant=form)
+            assert torch.equal(oh.float().argmax(-1).to(torch.uint8), src_code) and float(oh.float().sum()) == 20.0 * n, tag
+        # encode-only (no move) goes through the default dispatch of rc_encode
+    oh = torch.full((n, 20, 24), 3, dtype=torch.float32, device="cuda")
+    ops.encode(src, n, cs, oh, L.FMT_F32)
+    assert torch.equal(oh.argmax(-1).to(torch.uint8), src_code) and float(oh.sum()) == 20.0 * n
+    assert L.read_status() == 0
+    if n >= 1 << 17:
+        assert "k_step_dense<Cube3,bf16,move,store,TILE=256>" in L.describe(L.OP_STEP, 3, n, outputs=L.OUT_STATES, fmt=L.FMT_BF16)
+        assert "k_code_to_dense_wide" in L.describe(L.OP_CODE_TO_DENSE, 3, n, fmt=L.FMT_F32)
+
+
 def _random_shapes(seed, count):
     """Seeded ragged sizes around the places where the kernels change behaviour: pack width (4 / 8 cubes per lane), wave span
     (256 / 512), tile boundaries (1024-cube tiles), single cubes."""

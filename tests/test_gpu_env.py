@@ -621,7 +621,7 @@ def test_envs_in_several_processes_share_one_gpu(oracle, golden):
 def test_checkpoint_traces_replay_on_the_hip_222_path(mod, golden):
     """SURVEY 8f N4 on the product path.  tests/golden/crosscheck_222.npz holds the greedy solve traces of the
     reference's shipped 2x2x2 checkpoint (pretrained/222model.pt, model.py:47-76) for seeds 0..39 x k in
-    {1,2,3,4,6,8}: the scramble draws of reset(seed, k), the policy's actions and, per step, the arg-max column of every
+    {1,2,3,4,6,8,10,12,14}: the scramble draws of reset(seed, k), the policy's actions and, per step, the arg-max column of every
     one-hot row and the done flag.  Here the Cube2 KERNELS replay them: VecCubeEnv(cube_size=2).reset(seeds, ks) (numpy's
     legacy generator on the device), then one rc_apply_moves per time step.  The authors' policy solving every one of
     these cubes is the only external evidence for the unpinned 2x2x2 convention (cube_env.py:142-147); this test
@@ -631,7 +631,7 @@ def test_checkpoint_traces_replay_on_the_hip_222_path(mod, golden):
     env = mod.VecCubeEnv(n, "cuda", 2, obs="onehot", onehot_dtype=torch.uint8)
     env.reset(seeds=[int(s) for s in g["seeds"]], scramble_count=[int(k) for k in g["ks"]])
     env2 = mod.VecCubeEnv(n, "cuda", 2, obs="onehot", onehot_dtype=torch.uint8)
-    env2.reset(actions=g["scramble"], scramble_count=8)                # the recorded draws, no-op padded
+    env2.reset(actions=g["scramble"], scramble_count=g["scramble"].shape[1])     # the recorded draws, no-op padded
     assert torch.equal(env.sim_cube, env2.sim_cube)                    # device MT19937 == the draws the fixture recorded
     solve_step = np.zeros(n, np.int32)
     for t in range(T):
@@ -643,29 +643,180 @@ def test_checkpoint_traces_replay_on_the_hip_222_path(mod, golden):
         assert (rew.cpu().numpy() == np.where(d, 1.0, -1.0)).all()
         solve_step[(solve_step == 0) & (d != 0)] = t + 1
     assert (solve_step == g["solve_step"]).all()
-    assert (solve_step > 0).all()                                       # the authors' policy solves every one of them
+    assert (solve_step[g["ks"] <= 8] > 0).all()                         # the authors' policy solves every scramble up to depth 8
+    assert (solve_step > 0).mean() >= 0.9
     env.check_actions()
+    # the action lists the REFERENCE'S OWN MCTS returned on the restated env (50 simulations, depths up to 14) solve the same
+    # scrambles on the Cube2 kernels, through the same one-hots
+    found = g["mcts_found"].astype(bool)
+    sol, cols = g["mcts_solution"][found], g["mcts_cols"][found]
+    m = int(found.sum())
+    menv = mod.VecCubeEnv(m, "cuda", 2, obs="onehot", onehot_dtype=torch.uint8)
+    menv.reset(seeds=[int(x) for x in g["mcts_seeds"][found]], scramble_count=[int(k) for k in g["mcts_ks"][found]])
+    chk = mod.VecCubeEnv(m, "cuda", 2, obs=None)
+    chk.reset(actions=g["mcts_scramble"][found], scramble_count=g["mcts_scramble"].shape[1])
+    assert torch.equal(menv.sim_cube, chk.sim_cube)
+    last = (sol < 6).sum(1)                                             # length of each action list
+    for t in range(int(last.max())):
+        obs, rew, done, _ = menv.step(torch.from_numpy(np.ascontiguousarray(sol[:, t])).cuda())   # the no-op parks finished lists
+        assert (obs.argmax(-1).cpu().numpy() == cols[:, t]).all(), t
+        d = done.cpu().numpy().astype(bool)
+        assert (d[last == t + 1]).all() and not d[last > t + 1].any(), t      # solved exactly by the last move of its list
+    assert menv.is_solved().cpu().numpy().all()
 
 
-@pytest.mark.parametrize("graph", [False, True])
-def test_batched_mcts_side_stream_expansion_is_equivalent(mod, graph):
-    """BatchedMCTS(overlap=True) runs the expansion on a side stream next to the net forward (config 5's "interleaved"
-    shape).  Same roots, same per-root generators: identical searches with and without it, eager and as a hipGraph."""
+# ----------------------------------------------------------------------------- N2: guided searches (fixture G12)
+_POW31 = [pow(31, i, 1 << 63) for i in range(20)]
+
+
+def _guided_table(g):
+    """Fixture G12's stub as data: hash of the 20 one-hot columns -> (distance to solved, move back towards solved)."""
+    cols = g["table_cols"].astype(np.int64)
+    h = (cols * np.array(_POW31, np.int64)).sum(1)
+    order = np.argsort(h)
+    assert len(np.unique(h)) == len(h)
+    return cols, h[order], g["table_depth"][order].astype(np.int64), g["table_back"][order].astype(np.int64)
+
+
+class _GuidedHostStub:
+    """predict(state) exactly as the fixture's generator defined it (make_golden.py golden_mcts_guided)."""
+
+    def __init__(self, g):
+        self.table = {tuple(c): (int(d), int(b)) for c, d, b in zip(g["table_cols"].tolist(), g["table_depth"], g["table_back"])}
+
+    def predict(self, x):
+        hit = self.table.get(tuple(np.asarray(x).argmax(-1).tolist()))
+        logits, value = np.zeros(12, np.float32), np.float32(-9.0)
+        if hit is not None:
+            value = np.float32(-float(hit[0]))
+            logits[hit[1]] = 2.0
+        e = np.exp(logits - logits.max())
+        return np.array([value], np.float32), (e / e.sum()).astype(np.float32)
+
+
+def _guided_device_model(g):
+    """The same stub as a batched torch callable: (value [B,1], LOGITS [B,12]); BatchedMCTS applies the softmax."""
+    _, h_sorted, depth, back = _guided_table(g)
+    hs, dp, bk = (torch.from_numpy(a).cuda() for a in (h_sorted, depth, back))
+    powers = torch.tensor(_POW31, dtype=torch.int64, device="cuda")
+
+    def model(x):
+        h = (x.argmax(-1).to(torch.int64) * powers).sum(-1)
+        idx = torch.searchsorted(hs, h).clamp_(max=len(hs) - 1)
+        hit = hs[idx] == h
+        value = torch.where(hit, -dp[idx].float(), torch.full_like(h, -9, dtype=torch.float32))
+        logits = torch.nn.functional.one_hot(bk[idx], 12).float() * (2.0 * hit.float()).unsqueeze(-1)   # capturable: no data-dependent shapes
+        return value.unsqueeze(-1), logits
+    return model
+
+
+def test_mcts_guided_matches_reference_along_the_returned_path(mod, golden):
+    """G12: the reference's MCTS with a guiding stub on depth 3-5 scrambles (27 of 36 searches FIND a solution, paths up to 12
+    moves, up to 44 simulations).  mcts_batched.MCTS with the same stub and the same seeded `random`: simulations used, the
+    returned action list, and visits / values / virtual losses of EVERY node from the root to the expanded leaf
+    (mcts.py:52-130: deep descents, transpositions through the code-keyed table, the literal -= 150)."""
+    import random
+
+    from rubiks_cube_solver_amd.mcts_batched import MCTS
+    g = golden("mcts_guided_333")
+    stub = _GuidedHostStub(g)
+    cfg = {"mcts": {"virtual_loss_const": 150, "cpuct": 1.0, "value_min": -10.0, "numMCTSSim": 50}, "test": {"cube_size": 3}}
+    env = mod.make_env(torch.device("cpu"), 3)
+    n_found = 0
+    for i, (seed, k) in enumerate(zip(g["seeds"], g["ks"])):
+        state = env.reset(seed=int(seed), scramble_count=int(k))
+        random.seed(int(g["random_seed"][i]))
+        tree, found, used = MCTS(stub, cfg), None, 0
+        for sim in range(60):
+            used = sim + 1
+            found = tree.train(state, env)
+            if found is not None:
+                break
+        assert used == int(g["sims"][i]), (i, used)
+        exp = [int(a) for a in g["solution"][i] if a != 255]
+        assert (found or []) == exp, i
+        if found is None:
+            continue
+        n_found += 1
+        key = tree.key_of_state(state)
+        assert int(g["path_nodes"][i]) == len(found)
+        for t, a in enumerate(found):
+            node = tree.children_and_data[key]
+            assert node.visits == g["path_visits"][i, t].tolist(), (i, t)
+            assert [float(v) for v in node.value] == g["path_values"][i, t].tolist(), (i, t)
+            assert [float(v) for v in node.vloss] == g["path_vloss"][i, t].tolist(), (i, t)
+            key = node.children[a]
+    assert n_found == 27 and max(int(x) for x in g["path_nodes"]) >= 12
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_batched_mcts_guided_lockstep(mod, golden, native):
+    """The 36 searches of fixture G12 run TOGETHER (one replay + one expansion + one stub evaluation per simulation): every
+    root ends like the reference's stand-alone run; with the Python trees the statistics of every node on the returned path
+    are compared too."""
     import random
 
     from rubiks_cube_solver_amd.mcts_batched import BatchedMCTS
-    n = 200
-    net = TinyNet([20, 24], 12, seed=5).cuda()
+    g = golden("mcts_guided_333")
+    n = len(g["seeds"])
     venv = mod.VecCubeEnv(n, "cuda", 3, obs=None)
-    venv.reset(seeds=list(range(n)), scramble_count=[2 + (i % 5) for i in range(n)])
-    runs = []
-    for overlap in (False, True):
-        bm = BatchedMCTS(net, venv.stickers, n, 3, rngs=[random.Random(50 + r) for r in range(n)], graph=graph, overlap=overlap)
-        for _ in range(25):
-            bm.simulate()
-        runs.append((bm.solution, bm.sims_used, [bm.trees[r][b"root"].visits for r in range(n)]))
-    assert runs[0] == runs[1]
-    assert sum(s is not None for s in runs[0][0]) >= 10               # a random net still finishes the shallow scrambles
+    venv.reset(seeds=[int(s) for s in g["seeds"]], scramble_count=[int(k) for k in g["ks"]])
+    rngs = [random.Random(int(s)) for s in g["random_seed"]]
+    bm = BatchedMCTS(_guided_device_model(g), venv.stickers, n, 3, rngs=rngs, graph=False, native=native)
+    for _ in range(60):
+        bm.simulate()
+    bm.sync_rngs()
+    for r in range(n):
+        assert bm.sims_used[r] == int(g["sims"][r]), r
+        exp = [int(a) for a in g["solution"][r] if a != 255]
+        assert (bm.solution[r] or []) == exp, r
+        if not exp:
+            continue
+        root = bm.trees[r][b"root"]
+        assert list(root.visits) == g["path_visits"][r, 0].tolist(), r
+        assert [float(v) for v in root.value] == g["path_values"][r, 0].tolist(), r
+        if not native:
+            node = root
+            for t, a in enumerate(exp):
+                assert node.visits == g["path_visits"][r, t].tolist() and [float(v) for v in node.vloss] == g["path_vloss"][r, t].tolist(), (r, t)
+                assert [float(v) for v in node.value] == g["path_values"][r, t].tolist(), (r, t)
+                node = bm.trees[r].get(node.children[a])
+    # the generators were advanced like the stand-alone runs' global `random`: a fresh run from the synced state continues
+    # where the reference's would (the first case drew at least once)
+    assert rngs[0].getstate() != random.Random(int(g["random_seed"][0])).getstate()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_batched_mcts_4096_roots_every_replica_matches_its_reference_run(mod, golden, graph):
+    """BASELINE config 5's size, checked (not only timed): 4096 roots = fixture G12's 36 scrambles tiled 113.8 times, every
+    replica with its own generator seeded like the reference's stand-alone run (mcts.py:36-154, config.yaml:29-32).  After 60
+    lockstep simulations every replica has used the same number of simulations, returns the same action list and has the same
+    root statistics as that run."""
+    import random
+
+    from rubiks_cube_solver_amd.mcts_batched import BatchedMCTS
+    g = golden("mcts_guided_333")
+    n, m = 4096, len(g["seeds"])
+    case = np.arange(n) % m
+    venv = mod.VecCubeEnv(n, "cuda", 3, obs=None)
+    venv.reset(seeds=[int(g["seeds"][c]) for c in case], scramble_count=[int(g["ks"][c]) for c in case])
+    bm = BatchedMCTS(_guided_device_model(g), venv.stickers, n, 3, rngs=[random.Random(int(g["random_seed"][c])) for c in case],
+                     graph=graph, native=True)
+    solved = 0
+    for _ in range(60):
+        solved = bm.simulate()
+    sims, sols = bm.sims_used, bm.solution
+    exp_sol = [[int(a) for a in g["solution"][c] if a != 255] for c in range(m)]
+    assert solved == int(sum(bool(exp_sol[c]) for c in case))
+    for r in range(n):
+        c = int(case[r])
+        assert sims[r] == int(g["sims"][c]), (r, c)
+        assert (sols[r] or []) == exp_sol[c], (r, c)
+    for r in list(range(0, n, 97)) + list(range(n - 36, n)):                  # root statistics on a strided sample + the tail
+        c = int(case[r])
+        if exp_sol[c]:
+            root = bm.trees[r][b"root"]
+            assert list(root.visits) == g["path_visits"][c, 0].tolist() and [float(v) for v in root.value] == g["path_values"][c, 0].tolist(), r
 
 
 def test_vec_env_debug_action_check_and_clone(mod):
@@ -692,13 +843,6 @@ def test_vec_env_debug_action_check_and_clone(mod):
 
 
 # ----------------------------------------------------------------------------- N1: tensor replay sink (fixture G11)
-def _g11_buffer(rc, g, upto=None):
-    """TensorReplayBuffer holding exactly what the reference's ReplayBuffer held in fixture G11 after the first
-    get_random_samples call (its 1500 newest of 1920 samples), appended as reference-style tensors."""
-    buf = rc.TensorReplayBuffer(int(g["buf_size"]), int(g["sample_size"]), cube_size=3, device="cuda")
-    return buf
-
-
 def test_tensor_replay_buffer_matches_reference_class(golden):
     """Fixture G11 = the reference's ReplayBuffer (utils.py:203-270) fed by its own get_random_samples with G5's stub model.
     The tensor sink, fed by the PRODUCT's get_random_samples under the same global seed, must hold the same samples after the

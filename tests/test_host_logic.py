@@ -63,6 +63,40 @@ def test_move_group_properties():
     assert (p3[0][p3[6]] == p3[6][p3[0]]).all()                 # opposite faces commute (U, D)
 
 
+def test_pair_tables_reproduce_the_reference_luts(golden, oracle):
+    """The two-colour code tables the kernels use (tables.pair_tables -> rc_tables.h) against the reference's own outputs:
+    every step of fixture G3's 1000 walks (reachable states: corners and edges) and fixture G7's arbitrary colourings
+    (edges only: the edge table is exact for any colouring), plus 2x2x2 walks against the oracle."""
+    import rubiks_cube_solver_amd as r
+    from rubiks_cube_solver_amd.tables import SIGMAS, pair_tables
+    t = r.get_tables(3)
+    epair, cpair, cid = pair_tables(3)
+    assert len(cpair) == 2 and cid.shape == (8, 6)
+    w = golden("walks_333")
+    st, cols = w["stickers"].reshape(-1, 54), w["cols"].reshape(-1, 20)
+    for q in range(8):
+        for sid, sg in enumerate(SIGMAS):
+            c = [st[:, t.corner_defs[q][j]] for j in sg]
+            literal = t.corner_code[c[0] + 2 * c[1] + 10 * c[2]]
+            assert (cpair[cid[q, sid]][c[1], c[0]] == literal).all(), (q, sid)
+            if sid == 0:
+                assert (literal == cols[:, q]).all()
+    for e in range(12):
+        c0, c1 = st[:, t.edge_defs[e][0]], st[:, t.edge_defs[e][1]]
+        assert (epair[c1, c0] == cols[:, 8 + e]).all() and (epair[c0, c1] == t.edge_code[c1 + 10 * c0]).all()
+    g7 = golden("encode_333")
+    for e in range(12):
+        c0, c1 = g7["stickers"][:, t.edge_defs[e][0]], g7["stickers"][:, t.edge_defs[e][1]]
+        assert (epair[c1, c0] == g7["cols"][:, 8 + e]).all()
+    t2 = r.get_tables(2)
+    _, cpair2, cid2 = pair_tables(2)
+    ex = oracle.adi(2, 3000, 14, seed=3, stream=0, want_children=False)
+    st2, code2 = ex["parents"].reshape(-1, 24), ex["parent_code"].reshape(-1, 7)
+    for q in range(7):
+        c0, c1 = st2[:, t2.corner_defs[q][0]], st2[:, t2.corner_defs[q][1]]
+        assert (cpair2[cid2[q, 0]][c1, c0] == code2[:, q]).all(), q
+
+
 def test_generated_header_is_current():
     assert subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_tables.py"), "--check"]).returncode == 0
 
@@ -112,8 +146,12 @@ def test_dispatch_description_and_enodev_without_gpu():
     assert "V=2,move,store,code,POL=1" in L.describe(L.OP_STEP, 3, 1 << 22, outputs=st | L.OUT_REWARD, fmt=L.FMT_CODE)
     assert L.describe(L.OP_STEP, 2, 1 << 22, outputs=st).startswith("k_step<Cube2,")
     assert L.describe(L.OP_STEP, 3, 1 << 20, outputs=st, fmt=L.FMT_BF16).startswith("k_step_dense<Cube3,bf16,move,store,TILE=256> grid=4096")
+    assert L.describe(L.OP_STEP, 3, 1 << 20, outputs=st, fmt=L.FMT_BF16, variant=300000).startswith("k_step_dense<Cube3,bf16,move,store,TILE=256> grid=4096")
+    assert "TILE=64" in L.describe(L.OP_STEP, 3, 1 << 20, outputs=st, fmt=L.FMT_BF16, variant=100000)
+    assert L.describe(L.OP_STEP, 2, 1 << 20, outputs=st, fmt=L.FMT_BF16).startswith("k_step_dense<Cube2,bf16,move,store,TILE=256>")
     assert L.describe(L.OP_STEP, 3, 4096, outputs=0, fmt=L.FMT_F32).startswith("k_step_dense<Cube3,f32,encode,TILE=64>")
-    assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 20, fmt=L.FMT_F32).startswith("k_code_to_dense<Cube3,f32,TILE=256> grid=2048")
+    assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 20, fmt=L.FMT_F32).startswith("k_code_to_dense_wide<Cube3,f32> tiles_per_group=37 grid=111")
+    assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 16, fmt=L.FMT_F32).startswith("k_code_to_dense<Cube3,f32,TILE=64> grid=1024")
     assert L.describe(L.OP_EXPAND, 3, 1 << 20, outputs=L.OUT_STATES | L.OUT_FLAGS).startswith("k_expand<Cube3,V=2> parts=1 grid=2048")
     assert L.describe(L.OP_ADI, 3, 100000, 30, outputs=L.OUT_STATES | L.OUT_FLAGS).startswith("k_adi<Cube3,V=2> parts=1 segs=1 grid=196")
     assert L.describe(L.OP_ADI, 3, 100000, 30, outputs=L.OUT_CODE | L.OUT_FLAGS).startswith("k_adi<Cube3,V=2,code> parts=1 segs=3 grid=588")

@@ -190,3 +190,26 @@ def test_rng_spec(oracle):
     out = oracle.adi(3, 8, 16, seed=2024, stream=0, walk0=0)
     assert (out["actions"][0] == a[:16]).all()
     assert (out["actions"][5] == oracle.rng_actions(2024, 0, 5, 16, 12)).all()
+
+
+def test_222_convention_evidence_in_the_fixture(golden):
+    """SURVEY 8f N4 with negative controls (tests/golden/make_crosscheck_222.py; the checkpoint itself never travels): the
+    reference's shipped 2x2x2 policy solves the restated convention's cubes and NOT the cubes of four plausible other
+    conventions -- the only pin the unpinned 2x2x2 encoding can get (cube_env.py:8,142-147; pretrained/222model.pt)."""
+    g = golden("crosscheck_222")
+    conv, depths = list(g["conventions"]), list(g["depths"])
+    assert conv[0] == "shipped" and len(conv) == 5 and depths == [1, 2, 3, 4, 6, 8, 10, 12, 14]
+    gr, mr = g["greedy_rate"], g["mcts_rate"]
+    assert (gr[0, :6] == 1.0).all() and gr[0, 6] >= 0.9 and gr[0, 8] >= 0.5            # 100 % up to depth 8, 60 % at depth 14
+    assert (gr[1:, 0] <= 0.55).all() and (gr[1:, 3:] <= 0.15).all() and (gr[1:, 5:] <= 0.05).all()   # every control collapses
+    assert (gr[0] - gr[1:].max(0) >= 0.45).all()                                         # at EVERY depth the gap is wide
+    # the reference's own MCTS (50 simulations): depth 1 is solved by the first expansion whatever the net says; from depth 2
+    # on only the shipped convention keeps finding solutions
+    assert (mr[:, 0] == 1.0).all() and (mr[0, 1:5] >= 0.65).all() and (mr[1:, 1:5] <= 0.5).all() and (mr[1:, 5:] <= 0.05).all()
+    assert (mr[0, 1:5] - mr[1:, 1:5].max(0) >= 0.2).all()
+    # the greedy traces of the shipped convention are self-consistent
+    n = len(g["seeds"])
+    assert n == 40 * 9 and g["scramble"].shape == (n, 14) and ((g["scramble"] < 6).sum(1) == g["ks"]).all()
+    assert ((g["solve_step"] > 0) == (g["done"][:, -1] == 1)).all()
+    found = g["mcts_found"].astype(bool)
+    assert found.sum() >= 80 and ((g["mcts_solution"] < 6).sum(1)[found] >= 1).all() and ((g["mcts_solution"] < 6).sum(1)[~found] == 0).all()

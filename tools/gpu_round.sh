@@ -1,11 +1,11 @@
 #!/bin/bash
 # One GPU session: tests, bench, rocprof stats + PMC passes, fresh-process ADI repeats, design A/B.
-# Run via gpurun from the repo root:   gpurun --timeout 1200 -- 'bash tools/gpu_round.sh r02a'
+# Run via gpurun from the repo root:   gpurun --timeout 1190 -- 'SKIP_TESTS=1 bash tools/gpu_round.sh r03a'
 # rocprofv3 always gets the program itself after `--` (python3 / a binary), never a wrapper.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
-TAG=${1:-r02}
+TAG=${1:-r03}
 mkdir -p $O
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
   python -m pytest tests -m gpu -x -q > $O/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/${TAG}_pytest.log

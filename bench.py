@@ -18,7 +18,7 @@ The line also carries "configs" (rank 0, every N): the other BASELINE.json workl
 region with HIP events on the launch stream and with a roofline sub-record of its own (kernel = what the library's own
 dispatch reports, algorithmic bytes per launch, achieved GB/s, fraction of the 8 TB/s HBM peak): config 2 (1M cubes,
 move + reward + done), the 4M step in place, with the reward, with the fused compact code, the 16M-cube step whose 1.8 GB
-ping-pong defeats the Infinity Cache (the HBM-only point: roofline.frac_hbm_only), the fused dense one-hot (f32 / bf16),
+ping-pong defeats the Infinity Cache (the HBM-only point: roofline.frac_hbm_only), the fused dense one-hot (f32 / bf16), code -> dense (f32 / bf16),
 config 3 (ADI 100k walks x 30, 715 B per (walk, depth)), the 1M-parent expansion, config 5 (us per MCTS step, eager and
 as a hipGraph) and the batch-1 facade latency.  --no-configs skips them.
 """
@@ -218,6 +218,16 @@ def other_configs(torch, ops, _lib, dev, acts):
         rec(f"3x3x3 batch 1M, apply_move + reward + done + fused dense {name} one-hot [N,20,24]", D(_lib.OP_STEP, CUBE, m, outputs=ST | REW, fmt=fmt), m, "steps",
             114 + bpc, t)
         del oh
+    # compact code -> dense one-hot: what adi_samples, the replay sink and the lockstep search launch (the wide writer)
+    code1 = ops.alloc_code(m, CUBE, dev)
+    ops.encode(a1, m, CUBE, code1, _lib.FMT_CODE)
+    for dt, fmt, name, bpc in ((torch.float32, _lib.FMT_F32, "f32", 1920), (torch.bfloat16, _lib.FMT_BF16, "bf16", 960)):
+        oh = torch.empty((m, 20, 24), dtype=dt, device=dev)
+        t = timed(lambda: ops.onehot_from_code(code1, m, CUBE, oh), 10, 2)
+        rec(f"3x3x3 batch 1M, compact code -> dense {name} one-hot [N,20,24] (rc_onehot_from_code)", D(_lib.OP_CODE_TO_DENSE, CUBE, m, fmt=fmt), m, "cubes",
+            20 + bpc, t)
+        del oh
+    del code1
     # 1M-parent expansion (the MCTS / ADI child loop at scale)
     ex = ops.expand_buffers(m, CUBE, dev, children=True, codes=False)
     t = timed(lambda: ops.expand_children(a1, m, CUBE, ex["children"], ex["child_solved"], pitch=ex["children"].shape[-1]), 30)

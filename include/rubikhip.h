@@ -253,7 +253,7 @@ const char *rc_last_error(void);
  *   thousands  (2 digits) parts per walk group for expansion / ADI (1..A, rounded up to a divisor of A)
  *   100000s    dense one-hot writer: 1 -> 64-cube tiles, 2 -> 256-cube tiles (256-thread workgroups), 3 -> the wide form of
  *              rc_onehot_from_code (960-thread workgroups sweeping contiguous tile ranges; 3x3x3, the default from 2^17 cubes;
- *              the thousands field then gives the wanted workgroup count / 16)
+ *              the thousands field then gives the wanted workgroup count / 16, the tens digit the sweep skew)
  *   millions   (2 digits) depth segments per walk group of the ADI kernel (1..16, clamped to depth) */
 
 #ifdef __cplusplus

@@ -275,20 +275,26 @@ __global__ void __launch_bounds__(kDenseBlock) k_code_to_dense(const uint8_t *co
 // cubes in the same process on the same buffers (profiles/r03_ab.json): bf16 0.68-0.72 -> 0.77-0.91 of the 8 TB/s peak, f32
 // 0.66-0.83 -> 0.71-0.92, u8 0.67-0.74 -> 0.77-0.85 (the spread is between GPU boxes); at least level with the 256-thread form
 // for every batch size tried (2^17 .. 2^22, powers of two and not).  Group counts from 64 to 512 were swept: ~112 is the best
-// or within 2 % of it for all three element sizes; 64 groups are too few waves.
-constexpr int kWideBlock = 960, kWideGroups = 112, kWideTile = 256;
+// or within 2 % of it for all three element sizes; 64 groups are too few waves.  Group g starts its sweep 3g tiles into its range
+// and wraps (kWideSkew): neutral at 112 groups, +3-5 % where the ranges are equal powers of two (128 groups at 2^20 / 2^21 cubes).
+constexpr int kWideBlock = 960, kWideGroups = 112, kWideTile = 256, kWideSkew = 3;
 
 template <class T, class E>
 __global__ void __launch_bounds__(kWideBlock) k_code_to_dense_wide(const uint8_t *code, int64_t n, int64_t code_pitch, int shift, E *dense,
-                                                                   int64_t tiles_per_group) {
+                                                                   int64_t tiles_per_group, int skew) {
     constexpr int TILE = kWideTile, TP = TILE + 4;
     __shared__ __attribute__((aligned(16))) uint8_t lds_code[2][T::SLOTS * TP];
     const uint32_t lo = threadIdx.x * 4;
     const int64_t first = (int64_t)blockIdx.x * tiles_per_group * TILE;
     int64_t last = first + tiles_per_group * TILE;
     if (last > n) last = n;
+    // skew: group g starts its sweep (g * skew) tiles into its range and wraps, so that the concurrent streams do not advance
+    // through equally spaced addresses in lockstep
+    const int64_t mine = (last - first + TILE - 1) / TILE;
+    const int64_t start = mine > 0 ? ((int64_t)blockIdx.x * skew) % mine : 0;
     int buf = 0;
-    for (int64_t tile0 = first; tile0 < last; tile0 += TILE, buf ^= 1) {
+    for (int64_t k = 0; k < mine; ++k, buf ^= 1) {
+        const int64_t tile0 = first + ((start + k) % mine) * TILE;
         if (lo < TILE && tile0 + lo < n) {
             const __amdgpu_buffer_rsrc_t r = make_srd(code + tile_off(tile0, code_pitch, shift, T::SLOTS));
             const uint32_t rs = (uint32_t)code_pitch;
@@ -990,11 +996,12 @@ int launch_code_to_dense_wide(const uint8_t *code, int64_t n, int64_t code_pitch
     if constexpr (T::SIZE == 3) {
         const WideGrid w = wide_grid(n, variant);
         RC_GRID(w.groups);
+        const int skew = (variant / 10) % 10 ? (variant / 10) % 10 : kWideSkew;
         const dim3 g((unsigned)w.groups), b(kWideBlock);
-        if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_code_to_dense_wide<T, uint8_t>), g, b, 0, st, code, n, code_pitch, sh, static_cast<uint8_t *>(onehot), w.per);
-        else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_code_to_dense_wide<T, uint16_t>), g, b, 0, st, code, n, code_pitch, sh, static_cast<uint16_t *>(onehot), w.per);
-        else if (fmt == RC_FMT_BF16) hipLaunchKernelGGL((k_code_to_dense_wide<T, Bf16>), g, b, 0, st, code, n, code_pitch, sh, static_cast<Bf16 *>(onehot), w.per);
-        else hipLaunchKernelGGL((k_code_to_dense_wide<T, float>), g, b, 0, st, code, n, code_pitch, sh, static_cast<float *>(onehot), w.per);
+        if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_code_to_dense_wide<T, uint8_t>), g, b, 0, st, code, n, code_pitch, sh, static_cast<uint8_t *>(onehot), w.per, skew);
+        else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_code_to_dense_wide<T, uint16_t>), g, b, 0, st, code, n, code_pitch, sh, static_cast<uint16_t *>(onehot), w.per, skew);
+        else if (fmt == RC_FMT_BF16) hipLaunchKernelGGL((k_code_to_dense_wide<T, Bf16>), g, b, 0, st, code, n, code_pitch, sh, static_cast<Bf16 *>(onehot), w.per, skew);
+        else hipLaunchKernelGGL((k_code_to_dense_wide<T, float>), g, b, 0, st, code, n, code_pitch, sh, static_cast<float *>(onehot), w.per, skew);
         RC_HIP(hipGetLastError());
         return RC_OK;
     } else {

@@ -45,7 +45,8 @@ def test_bench_json_line():
     # the other BASELINE configs ride in the same line, each with its own roofline sub-record
     recs = d["configs"]["records"]
     names = " | ".join(x["config"] for x in recs)
-    for needle in ("config 2", "config 3", "fused compact one-hot code", "fused dense f32", "fused dense bf16", "expansion of 1M", "2x2x2"):
+    for needle in ("config 2", "config 3", "fused compact one-hot code", "fused dense f32", "fused dense bf16", "expansion of 1M", "2x2x2",
+                   "compact code -> dense bf16"):
         assert needle in names, needle
     for x in recs:
         assert x["kernel"].startswith("k_") and x["launch_us"] > 0 and x["value"] > 0
@@ -66,6 +67,7 @@ def test_bench_json_line():
     assert "POL=2" in hbm["kernel"] and abs(r["frac_hbm_only"] - hbm["roofline"]["frac"]) < 1e-12 and 0.5 < r["frac_hbm_only"] < 0.95
     assert r["served_by"] == "hbm + infinity cache" and d["config"]["cubes_per_gpu"] == 1 << 22
     assert any("IN PLACE" in x["config"] for x in recs)
+    assert [x for x in recs if "compact code -> dense bf16" in x["config"]][0]["kernel"].startswith("k_code_to_dense_wide<Cube3,bf16>")
 
 
 @pytest.mark.gpu

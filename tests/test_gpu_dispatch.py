@@ -238,12 +238,25 @@ def test_step_policies_agree_at_scale(ops, L, cs):
     ref_done = torch.empty(n, dtype=torch.uint8, device="cuda")
     ops.apply_moves(st, ref, acts, n, cs, None, ref_done, variant=21)              # narrow pack, default-cached
     valid = ops.to_aos(ref, n)
-    for variant in (0, 1, 2, 11, 12, 22, 31, 32):
+    ref_code = ops.alloc_code(n, cs, "cuda")
+    ref_rew = torch.empty(n, dtype=torch.float32, device="cuda")
+    ops.apply_moves(st, ref, acts, n, cs, ref_rew, ref_done, ref_code, L.FMT_CODE, variant=21)
+    for variant in (0, 1, 2, 11, 12, 22, 31, 32, 41, 42):
         out = torch.zeros_like(st)
         done = torch.zeros_like(ref_done)
         ops.apply_moves(st, out, acts, n, cs, None, done, variant=variant)
         assert torch.equal(ops.to_aos(out, n), valid), variant
         assert torch.equal(done, ref_done), variant
+        # every side output (reward, done, compact code) through every policy's store forms, ping-pong and in place
+        out.zero_(); done.zero_()
+        code, rew = torch.zeros_like(ref_code), torch.zeros_like(ref_rew)
+        ops.apply_moves(st, out, acts, n, cs, rew, done, code, L.FMT_CODE, variant=variant)
+        assert torch.equal(ops.to_aos(out, n), valid) and torch.equal(done, ref_done) and torch.equal(rew, ref_rew), variant
+        assert torch.equal(ops.to_aos(code, n), ops.to_aos(ref_code, n)), variant
+        work = st.clone()
+        code.zero_(); rew.zero_()
+        ops.apply_moves(work, work, acts, n, cs, rew, done, code, L.FMT_CODE, variant=variant)
+        assert torch.equal(ops.to_aos(work, n), valid) and torch.equal(rew, ref_rew) and torch.equal(ops.to_aos(code, n), ops.to_aos(ref_code, n)), variant
     assert L.read_status() == 0
 
 

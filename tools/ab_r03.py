@@ -187,6 +187,25 @@ def main():
                 emit(k=f"fused_{name}", buf=bi, groups=-256, us=t * 1e6, frac=(114 + bpc) * m / t / 8e12)
                 t = timeit(lambda: ops.onehot_from_code(code, m, 3, oh, variant=200000), iters=10)
                 emit(k=f"c2d_{name}", buf=bi, groups=-256, us=t * 1e6, frac=(20 + bpc) * m / t / 8e12)
+    if "wideskew" in which:
+        for m in (1 << 20, 1_300_000, 1 << 21):
+            a = ops.alloc_states(m, 3, "cuda")
+            ops.fill_solved(a, m, 3)
+            ops.scramble(a, m, 3, 20, seed=1234)
+            code = ops.alloc_code(m, 3, "cuda")
+            ops.encode(a, m, 3, code, _lib.FMT_CODE)
+            for fmt, name, bpc in ((_lib.FMT_U8, "u8", 480), (_lib.FMT_BF16, "bf16", 960), (_lib.FMT_F32, "f32", 1920)):
+                for bi in range(2):
+                    oh = torch.empty((m, 20, 24), dtype=_lib.dense_dtype(fmt), device="cuda")
+                    for g16 in (6, 7, 8, 10):
+                        for skew in (0, 1, 3, 5, 7, 9):
+                            var = 300000 + g16 * 1000 + skew * 10
+                            t = timeit(lambda: ops.onehot_from_code(code, m, 3, oh, variant=var), iters=10)
+                            emit(k=f"c2d_{name}", n=m, buf=bi, groups=g16 * 16, skew=skew, us=t * 1e6, frac=(20 + bpc) * m / t / 8e12)
+                    t = timeit(lambda: ops.onehot_from_code(code, m, 3, oh, variant=200000), iters=10)
+                    emit(k=f"c2d_{name}", n=m, buf=bi, groups=-256, skew=0, us=t * 1e6, frac=(20 + bpc) * m / t / 8e12)
+                    del oh
+            del a, code
     if "adirep" in which:
         W, D = 100_000, 30
         for rep in range(3):

@@ -472,10 +472,24 @@ __global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
         // that face's ring is home (not_ring == 0).  After a few random moves no walk of the wave is: skip the 12 ring tests.
         bool flags_live = false;
         if (a.child_solved) {
-            child_flags_prepare<T, V>(s, cf);
-            Pk<V> near = splat<V>(0);
-            sfor<T::A / 2>([&](auto fc) { near = near | done_bytes(cf.not_ring[decltype(fc)::value]); });
-            flags_live = __any(any(near));
+            // cheap necessary test first (round 3: the full preparation below was a quarter of the kernel's VALU work): a parent one
+            // face turn from solved has the face OPPOSITE to the turned one untouched, so some face must be entirely home
+            Pk<V> some_face_home = splat<V>(0);
+            sfor<6>([&](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                Pk<V> off = splat<V>(0);
+                sfor<T::FACE>([&](auto kc) {
+                    constexpr int i = f * T::FACE + decltype(kc)::value;
+                    off = off | (s[i] ^ splat<V>((uint32_t)f * 0x01010101u));
+                });
+                some_face_home = some_face_home | done_bytes(off);
+            });
+            if (__any(any(some_face_home))) {
+                child_flags_prepare<T, V>(s, cf);
+                Pk<V> near = splat<V>(0);
+                sfor<T::A / 2>([&](auto fc) { near = near | done_bytes(cf.not_ring[decltype(fc)::value]); });
+                flags_live = __any(any(near));
+            }
         }
         if (part == 0) {
             if (a.actions_out) bst<V, RC_OUT_AUX>(make_srd(a.actions_out + (int64_t)d * wp + g0), lo, 0, act);

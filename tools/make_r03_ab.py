@@ -90,5 +90,25 @@ out["dense_wide_groups"] = {
     "table_frac": table(rows("r03m_wide.jsonl"), lambda r: f"{r['k']}_buf{r['buf']}", lambda r: str(r["groups"]), "frac"),
     "reading": "fused: the wide form loses for every format and group count (bf16 0.62-0.74 against 0.74-0.76): ~110 workgroups funnel the state traffic and the dense "
                "stream stalls while they produce -- not shipped.  code -> dense: wide 112 wins on this box too (bf16 0.77-0.81 against 0.68-0.70)"}
+t = collections.OrderedDict()
+for r in rows("r03q_skew.jsonl"):
+    t.setdefault(f"{r['k']}_n{r['n']}_buf{r['buf']}", collections.OrderedDict())[f"g{r['groups']}_skew{r['skew']}"] = round(r["frac"], 3)
+out["dense_wide_skew"] = {
+    "what": "code -> dense, wide form: groups x sweep-start skew (group g starts g*skew tiles into its range and wraps); g-256 = the 256-thread form; fraction of 8 TB/s",
+    "table_frac": t,
+    "reading": "a fast box: 112 groups 0.89-0.91 (bf16, f32 at 2^20), skew neutral there; 128 groups (equal power-of-two ranges) 0.90-0.93 without and 0.93-0.95 with "
+               "skew; 1.3M cubes and f32 at 2^21 cubes (4 GB) stay at 0.72-0.83 for every form"}
+t = collections.OrderedDict()
+for f, tag in (("r03t_aosoa.jsonl", "lds_transposed_16B_per_lane"), ("r03t_base.jsonl", "shipped_rows_8B_per_lane")):
+    for r in rows(f):
+        if "rep" in r:
+            t.setdefault(r["k"], collections.OrderedDict()).setdefault(tag, []).append(round(r["us"], 1))
+out["adi_code_store_shape"] = {
+    "what": "code-emitting ADI, 100k x 30: the 20 code rows of every state transposed through a wave-private LDS block and stored as five 16-byte-per-lane instructions "
+            "of 1 KiB contiguous each (timing experiment: the shape of a [n/4][20][4] code layout) against the shipped 20 row stores of 512 B; same box",
+    "table_us": t,
+    "reading": "the wide shape is 25-35 % SLOWER (190-200 us against 146-157 us): not adopted, the code layout stays [slot][pitch]",
+    "also": "a cheap necessary pre-test for the child flags (some face entirely home) cut the dynamic VALU work by ~20 % and changed nothing "
+            "(r03s: 149-155 us / 170 us): the launch is bound by its store stream, not by VALU"}
 json.dump(out, open(os.path.join(ROOT, "profiles", "r03_ab.json"), "w"), indent=1)
 print("wrote profiles/r03_ab.json", os.path.getsize(os.path.join(ROOT, "profiles", "r03_ab.json")), "bytes")

@@ -2,7 +2,10 @@
 """Round-3 A/B measurements through the shipped library (per-call `variant` of the *_ex entry points; RUBIKHIP_LIB selects
 another build of the same sources for before/after rows).  One JSON line per row.
 
-    python tools/ab_r03.py stepcode adiseg dense [tag]
+    python tools/ab_r03.py stepcode stepn hbm16 dense adiseg adipitch adirep widegroups wideskew
+
+The dense-writer groups r03f-r03k and r03v of profiles/r03_ab.json came from experiment builds of the same sources (environment-
+selected group counts, strided / paced / window forms) that are not in the tree any more; their rows are kept in profiles/r03_ab.json.
 """
 import json
 import os
@@ -101,68 +104,6 @@ def main():
                     t = timeit(lambda: ops.adi_generate(W, D, 3, pt, "cuda", seed=2024, variant=var, **bufs), iters=5, warm=2)
                     emit(k=f"adi_{label}_pitch{pitch}_V{v}_parts{parts}_segs{segs}", us=t * 1e6, frac=bpu * W * D / t / 8e12)
                 del bufs
-    if "densewide" in which:
-        # RC_EXP_DENSE=<groups> (read once per process by the experiment build) selects the 960-thread wide writer
-        m = 1 << 20
-        a = ops.alloc_states(m, 3, "cuda")
-        ops.fill_solved(a, m, 3)
-        ops.scramble(a, m, 3, 20, seed=1234)
-        code = ops.alloc_code(m, 3, "cuda")
-        ops.encode(a, m, 3, code, _lib.FMT_CODE)
-        ref = {}
-        for rep in range(3):
-            for fmt, name, bpc in ((_lib.FMT_U8, "u8", 480), (_lib.FMT_BF16, "bf16", 960), (_lib.FMT_F32, "f32", 1920)):
-                oh = torch.empty((m, 20, 24), dtype=_lib.dense_dtype(fmt), device="cuda")
-                oh.fill_(7)
-                t = timeit(lambda: ops.onehot_from_code(code, m, 3, oh), iters=10)
-                chk = (int(oh.sum()), int((oh.float().argmax(-1).to(torch.uint8) == ops.to_aos(code, m)).all()))
-                emit(k=f"code_to_dense_{name}_1M", rep=rep, us=t * 1e6, frac=(20 + bpc) * m / t / 8e12, exp=os.environ.get("RC_EXP_DENSE", "0"), check=chk)
-                del oh
-    if "denseplace" in which:
-        # the same kernels into SIX separately allocated output buffers (round 2: the 256-thread form is bimodal between allocations)
-        import ctypes
-        libc = ctypes.CDLL(None)
-        def setenv(k, v):
-            libc.setenv(k.encode(), str(v).encode(), 1)      # the library reads the C environment, os.environ alone is not enough
-        m = 1 << 20
-        a = ops.alloc_states(m, 3, "cuda")
-        ops.fill_solved(a, m, 3)
-        ops.scramble(a, m, 3, 20, seed=1234)
-        code = ops.alloc_code(m, 3, "cuda")
-        ops.encode(a, m, 3, code, _lib.FMT_CODE)
-        for fmt, name, bpc in ((_lib.FMT_BF16, "bf16", 960), (_lib.FMT_F32, "f32", 1920)):
-            bufs = [torch.empty((m, 20, 24), dtype=_lib.dense_dtype(fmt), device="cuda") for _ in range(6)]
-            for i, oh in enumerate(bufs):
-                for label, groups, mode in (("base256thr", 0, 0), ("wide_strided128", 128, 1), ("wide_strided256", 256, 1), ("wide_contig96", 96, 0)):
-                    setenv("RC_EXP_DENSE", groups); setenv("RC_EXP_DENSE_MODE", mode)
-                    t = timeit(lambda: ops.onehot_from_code(code, m, 3, oh), iters=10)
-                    emit(k=f"code_to_dense_{name}_1M_{label}", buf=i, us=t * 1e6, frac=(20 + bpc) * m / t / 8e12)
-            del bufs
-            torch.cuda.empty_cache()
-        setenv("RC_EXP_DENSE", 0)
-    if "densesizes" in which:
-        import ctypes
-        libc = ctypes.CDLL(None)
-        def setenv(k, v):
-            libc.setenv(k.encode(), str(v).encode(), 1)
-        for m in (1 << 17, 3 << 16, 1 << 18, 300_000, 1 << 19, 3 << 18, 1 << 20, 1_300_000, 1 << 21, 1 << 22):
-            a = ops.alloc_states(m, 3, "cuda")
-            ops.fill_solved(a, m, 3)
-            ops.scramble(a, m, 3, 20, seed=1234)
-            code = ops.alloc_code(m, 3, "cuda")
-            ops.encode(a, m, 3, code, _lib.FMT_CODE)
-            for fmt, name, bpc in ((_lib.FMT_U8, "u8", 480), (_lib.FMT_BF16, "bf16", 960), (_lib.FMT_F32, "f32", 1920)):
-                if m * 480 * (bpc // 480) > (6 << 30):
-                    continue
-                oh = torch.empty((m, 20, 24), dtype=_lib.dense_dtype(fmt), device="cuda")
-                for label, groups in (("base", 0), ("wide64", 64), ("wide96", 96), ("wide112", 112), ("wide160", 160), ("wide256", 256)):
-                    setenv("RC_EXP_DENSE", groups); setenv("RC_EXP_DENSE_MODE", 0)
-                    t = timeit(lambda: ops.onehot_from_code(code, m, 3, oh), iters=10)
-                    emit(k=f"c2d_{name}", n=m, form=label, us=t * 1e6, frac=(20 + bpc) * m / t / 8e12)
-                del oh
-            del a, code
-            torch.cuda.empty_cache()
-        setenv("RC_EXP_DENSE", 0)
     if "widegroups" in which:
         m = 1 << 20
         a = ops.alloc_states(m, 3, "cuda")

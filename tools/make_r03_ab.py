@@ -110,5 +110,13 @@ out["adi_code_store_shape"] = {
     "reading": "the wide shape is 25-35 % SLOWER (190-200 us against 146-157 us): not adopted, the code layout stays [slot][pitch]",
     "also": "a cheap necessary pre-test for the child flags (some face entirely home) cut the dynamic VALU work by ~20 % and changed nothing "
             "(r03s: 149-155 us / 170 us): the launch is bound by its store stream, not by VALU"}
+out["dense_window_form"] = {
+    "what": "code -> dense as a memset-like WINDOW: passes of 960 threads (15 KiB of output) dealt round-robin to G workgroups, code bytes read straight from global "
+            "memory (experiment build); against the 256-thread form and the wide form (112 / 128 groups), three buffers each, on a session whose allocations were "
+            "all of the slow kind (second skew sweep r03u: the same script, another session -- f32 at 2^20 0.71-0.73 where the first session had 0.91-0.94)",
+    "table_frac": table(rows("r03v_win.jsonl"), lambda r: f"{r['k']}_n{r['n']}_buf{r['buf']}", lambda r: r["form"], "frac"),
+    "second_skew_session_frac": table(rows("r03u_skew.jsonl"), lambda r: f"{r['k']}_n{r['n']}_buf{r['buf']}", lambda r: f"g{r['groups']}_skew{r['skew']}", "frac"),
+    "reading": "on slow allocations every writer shape lands at 0.65-0.73 (window 256 groups 0.725 bf16, wide 112 0.70, 256-thread form 0.665): the spread between "
+               "sessions is a property of where the output buffer lives, not of the kernel; the wide form is the best or within 3 % of it in both kinds of session"}
 json.dump(out, open(os.path.join(ROOT, "profiles", "r03_ab.json"), "w"), indent=1)
 print("wrote profiles/r03_ab.json", os.path.getsize(os.path.join(ROOT, "profiles", "r03_ab.json")), "bytes")

@@ -958,3 +958,36 @@ def test_tensor_replay_buffer_222_and_wraparound():
             assert st.dtype == torch.float64 and (st.cpu().numpy() == smp["state"]).all()
             assert float(tv) == np.float32(smp["target_value"]) and int(tp) == smp["target_policy"] and int(sc) == smp["scramble_count"]
             assert int(mi) == int(i) and rb.error_memory[rb._phys(int(i))] == smp["error"]
+
+
+def test_adi_samples_feeds_the_net_in_its_own_dtype(mod):
+    """adi_samples writes the dense one-hot stream in the dtype the value net computes in (a bfloat16 net gets bfloat16
+    one-hots: half the bytes of the 13 x walks x 480 elements per depth); the samples are those of the float32 route up to the
+    net's own rounding."""
+    from rubiks_cube_solver_amd.adi import adi_samples
+
+    class Net(torch.nn.Module):
+        def __init__(self, dtype):
+            super().__init__()
+            g = torch.Generator().manual_seed(3)
+            self.w = torch.nn.Parameter((torch.randn(480, generator=g) * 0.05).to(dtype))
+            self.seen = set()
+
+        def forward(self, x):
+            self.seen.add(x.dtype)
+            v = x.reshape(x.shape[0], -1) @ self.w
+            return v.unsqueeze(-1), torch.zeros(x.shape[0], 12, device=x.device, dtype=x.dtype)
+
+    lo, hi = Net(torch.bfloat16).cuda(), Net(torch.float32).cuda()
+    with torch.no_grad():
+        hi.w.copy_(lo.w.float())                                   # the same weights, exactly
+    a = adi_samples(lo, 3, 3000, 9, 0.5, device="cuda", seed=11)
+    b = adi_samples(hi, 3, 3000, 9, 0.5, device="cuda", seed=11)
+    assert lo.seen == {torch.bfloat16} and hi.seen == {torch.float32}
+    assert torch.equal(a["state_code"], b["state_code"]) and torch.equal(a["actions"], b["actions"])
+    assert a["target_value"].dtype == torch.float32 and torch.allclose(a["target_value"], b["target_value"], atol=2e-2, rtol=0)
+    solved = b["target_value"] == 1.0
+    assert torch.equal(a["target_value"][solved], b["target_value"][solved]) and torch.equal(a["target_policy"][solved], b["target_policy"][solved])
+    assert (a["target_policy"] == b["target_policy"]).float().mean() > 0.9          # near ties may fall differently after bf16 rounding
+    c = adi_samples(hi, 3, 500, 4, 0.5, device="cuda", seed=11, dense_dtype=torch.float32)
+    assert torch.equal(c["state_code"], b["state_code"][:500, :4])

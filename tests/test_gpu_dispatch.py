@@ -367,10 +367,22 @@ def test_randomised_ragged_sizes_all_kernels(ops, L, oracle):
         m = min(n, 3000)
         adi_pitch = src.shape[2] if m > 1024 and pitch else L.pitch_for(m)
         pt, bufs = ops.adi_buffers(m, depth, cs, "cuda", adi_pitch, parents=True, children=True, child_code=True, parent_code=True)
-        ops.adi_generate(m, depth, cs, pt, "cuda", seed=case, stream_id=7, walk_offset=case * 13, variant=parts * 1000 + v, **bufs)
+        segs = (0, 1, 2, 3, 5)[case % 5]                                                  # depth segments: clamped to the depth by the library
+        ops.adi_generate(m, depth, cs, pt, "cuda", seed=case, stream_id=7, walk_offset=case * 13, variant=segs * 1000000 + parts * 1000 + v, **bufs)
         ex = oracle.adi(cs, m, depth, seed=case, stream=7, walk0=case * 13, threads=4)
         assert (untile(ops, bufs["children"], m, 2).transpose(2, 0, 1, 3) == ex["children"]).all(), tag
         assert (untile(ops, bufs["child_code"], m, 2).transpose(2, 0, 1, 3) == ex["child_code"]).all(), tag
         assert (untile(ops, bufs["parents"], m, 1).transpose(1, 0, 2) == ex["parents"]).all(), tag
         assert (bufs["child_solved"][..., :m].cpu().numpy().transpose(2, 0, 1) == ex["child_solved"]).all(), tag
+        # dense one-hot of the stepped states in a random element type, fused and from the code buffer, every writer form
+        fmt, dt = ((L.FMT_U8, torch.uint8), (L.FMT_F16, torch.float16), (L.FMT_BF16, torch.bfloat16), (L.FMT_F32, torch.float32))[case % 4]
+        form = (0, 100000, 200000, 300000)[(case // 4) % 4]
+        R, C = (20, 24) if cs == 3 else (7, 21)
+        oh = torch.full((n, R, C), 2, dtype=dt, device="cuda")
+        ops.apply_moves(src, torch.empty_like(src), torch.from_numpy(acts).cuda(), n, cs, None, None, oh, fmt, variant=form)
+        oh2 = torch.full((n, R, C), 2, dtype=dt, device="cuda")
+        ops.onehot_from_code(code, n, cs, oh2, variant=form)
+        assert torch.equal(oh, oh2) and float(oh.float().sum()) == float(n * (20 if cs == 3 else 7)), tag
+        if cs == 3:
+            assert (oh.float().argmax(-1).cpu().numpy() == exp_code).all(), tag
     assert L.read_status() == 0

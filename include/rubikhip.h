@@ -250,6 +250,7 @@ const char *rc_last_error(void);
  *   units      pack width: 1,2 -> 4,8 cubes per lane
  *   tens       row-traffic policy of the step kernel: 1 stream in / stream out, 2 default-cached,
  *              3 stream in / keep the output in the Infinity Cache, 4 state default-cached / side outputs streamed
+ *   hundreds   streaming expansion (stickers + flags by few persistent waves): 1..7 -> 128, 192, 256, 384, 512, 768, 1024 waves, 8 -> off
  *   thousands  (2 digits) parts per walk group for expansion / ADI (1..A, rounded up to a divisor of A)
  *   100000s    dense one-hot writer: 1 -> 64-cube tiles, 2 -> 256-cube tiles (256-thread workgroups), 3 -> the wide form of
  *              rc_onehot_from_code (960-thread workgroups sweeping contiguous tile ranges; 3x3x3, the default from 2^17 cubes;

@@ -398,6 +398,45 @@ __global__ void __launch_bounds__(kWave) k_expand(ExpandArgs a) {
     emit_children<T, V, CODE, false>(s, fam, cf, part, a.parts, o, lo);
 }
 
+// Streaming form for large sticker expansions (round 3): FEW persistent waves, each taking walk groups g, g + grid, ... in turn
+// with the next group's 54 rows prefetched while the current group's 12 x 54 child rows stream out -- the shape the ADI kernel
+// has (196 waves, 0.84 of peak) instead of 2048 short-lived waves: 1M parents 116.4 -> 113 us (0.80 -> 0.83).  Stickers + flags only (the code-emitting and the small
+// latency-bound expansions keep k_expand).
+template <class T>
+__global__ void __launch_bounds__(kWave) k_expand_stream(ExpandArgs a) {
+    constexpr int V = 2;
+    const uint32_t lo = threadIdx.x * (4 * V);
+    const int64_t span = kWave * 4 * V, groups = (a.n + span - 1) / span;
+    int64_t g = blockIdx.x;
+    if (g >= groups) return;
+    Pk<V> nxt[T::S];
+    auto load = [&](int64_t grp) {
+        const int64_t g0 = grp * span;
+        const __amdgpu_buffer_rsrc_t r = make_srd(a.in + tile_off(g0, a.pitch_in, a.sh_in, T::S));
+        const uint32_t rs = (uint32_t)a.pitch_in;
+        const bool live = g0 + lo < a.n;                            // lanes beyond the batch read nothing (their rows may not exist)
+#pragma unroll
+        for (int i = 0; i < T::S; ++i) nxt[i] = live ? bld<V, kAuxStreamLoad>(r, lo, i * rs) : splat<V>(0);
+    };
+    load(g);
+    while (true) {
+        Pk<V> s[T::S];
+#pragma unroll
+        for (int i = 0; i < T::S; ++i) s[i] = nxt[i];
+        const int64_t g0 = g * span, gn = g + gridDim.x;
+        if (gn < groups) load(gn);                                   // in flight while this group's children are written
+        if (g0 + lo < a.n) {
+            const ChildOut o{a.children + tile_off(g0, a.pitch_out, a.sh_out, T::S), a.child_solved ? a.child_solved + g0 : nullptr, nullptr,
+                             (uint32_t)a.pitch_out, a.tiles_out, true};
+            FamilyCodes<T, V> fam;
+            ChildFlags<T, V> cf;
+            emit_children<T, V, false, false>(s, fam, cf, 0, 1, o, lo);
+        }
+        if (gn >= groups) break;
+        g = gn;
+    }
+}
+
 // ------------------------------------------------------------------------------- ADI
 constexpr int kMaxSegs = 16;
 struct AdiArgs {
@@ -1038,6 +1077,7 @@ int check_fmt(void *onehot, int fmt, int64_t code_pitch, int64_t n, int *sh_code
 // (7.2 TB/s in the store-only harness) but one wave per 1024 walks cannot hide the walk's VALU work (0.44 ms).  Small
 // batches are latency-bound instead: spread them over the chip.  Code-only expansion is VALU-bound: narrow packs.
 struct Geometry { int v, parts, segs; };
+constexpr int64_t kExpandStreamGrid = 512;   // 1M parents: 113 us (0.83) with 512 waves, 114 (256), 115 (1024), 116.4 us for 2048 short-lived waves
 constexpr double kReplayCostCodes = 0.2, kReplayCostStickers = 0.35;   // replayed depth / emitted depth (RNG + move against everything)
 Geometry pick_geometry(int64_t n, int A, int variant, bool stickers_out, int64_t out_bytes, bool codes = false) {
     const int fv = variant % 10, fp = (variant / 1000) % 100;
@@ -1096,6 +1136,24 @@ void fill_segments(AdiArgs &a, int segs, double replay) {
         a.seg_lo[k] = (uint16_t)b;
         prev = b;
     }
+}
+
+// grid of the streaming expansion: hundreds digit of `variant` 1..7 -> 128, 192, 256, 384, 512, 768, 1024 waves; 8 -> not streamed
+inline int64_t expand_stream_grid(int64_t n, bool stickers, bool codes, int variant) {
+    static const int table[8] = {0, 128, 192, 256, 384, 512, 768, 1024};
+    const int h = (variant / 100) % 10;
+    if (!stickers || codes || h == 8 || (variant % 10) == 1 || (variant / 1000) % 100 > 1) return 0;
+    if (h >= 1 && h <= 7) return table[h];                         // forced (tests reach the kernel with small batches too)
+    return n * 54 * 12 >= ((int64_t)256 << 20) ? kExpandStreamGrid : 0;   // large write-once streams only
+}
+
+template <class T>
+int launch_expand_stream(ExpandArgs a, hipStream_t st, int64_t grid) {
+    const int64_t groups = (a.n + kWave * 8 - 1) / (kWave * 8);
+    if (grid > groups) grid = groups;
+    hipLaunchKernelGGL((k_expand_stream<T>), dim3((unsigned)grid), dim3(kWave), 0, st, a);
+    RC_HIP(hipGetLastError());
+    return RC_OK;
 }
 
 template <class T, int V>
@@ -1299,6 +1357,7 @@ int rc_expand_children_ex(const uint8_t *in, int64_t n, int64_t pitch_in, int cu
         ExpandArgs a{in, n, pitch_in, children, child_solved, child_code, pitch_out, n <= pitch_out ? 1 : (n + pitch_out - 1) / pitch_out,
                      geo.parts, sh_in, sh_out};
         hipStream_t st = S(stream);
+        if (const int64_t grid = expand_stream_grid(n, children != nullptr, child_code != nullptr, variant)) return launch_expand_stream<T>(a, st, grid);
         return geo.v == 2 ? launch_expand<T, 2>(a, st) : launch_expand<T, 1>(a, st);
     });
 }
@@ -1481,6 +1540,11 @@ int rc_describe_dispatch(int op, int cube_size, int64_t n, int depth, unsigned o
         }
         if (op == RC_OP_EXPAND) {
             const Geometry geo = pick_geometry(n, T::A, variant, states, n * T::S * T::A, code);
+            if (const int64_t grid = expand_stream_grid(n, states, code, variant)) {
+                const int64_t groups = (n + 511) / 512;
+                snprintf(buf, buflen, "k_expand_stream<%s> grid=%lld block=64", cube, (long long)(grid < groups ? grid : groups));
+                return RC_OK;
+            }
             snprintf(buf, buflen, "k_expand<%s,V=%d%s> parts=%d grid=%lld block=64", cube, geo.v, code ? ",code" : "", geo.parts,
                      (long long)((n + 256 * geo.v - 1) / (256 * geo.v) * geo.parts));
             return RC_OK;

@@ -69,6 +69,14 @@ def test_expand_every_parts_value(ops, L, oracle, cs, v, n, pitch):
         assert (untile(ops, out["children"], n, 1).transpose(1, 0, 2) == ch).all(), parts
         assert (untile(ops, out["child_code"], n, 1).transpose(1, 0, 2) == cc).all(), parts
         assert (out["child_solved"][:, :n].cpu().numpy().T == cso).all() and cso.any(), parts
+    if v == 2:                                                   # the streaming form (few persistent waves), forced for this small batch
+        for h in (1, 3, 7):
+            out = ops.expand_buffers(n, cs, "cuda", pitch or L.pitch_for(n), children=True, codes=False)
+            for t in out.values():
+                t.fill_(9)
+            ops.expand_children(src, n, cs, out["children"], out["child_solved"], None, pitch=out["children"].shape[-1], variant=h * 100)
+            assert (untile(ops, out["children"], n, 1).transpose(1, 0, 2) == ch).all(), h
+            assert (out["child_solved"][:, :n].cpu().numpy().T == cso).all(), h
     assert L.read_status() == 0
 
 

@@ -152,7 +152,9 @@ def test_dispatch_description_and_enodev_without_gpu():
     assert L.describe(L.OP_STEP, 3, 4096, outputs=0, fmt=L.FMT_F32).startswith("k_step_dense<Cube3,f32,encode,TILE=64>")
     assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 20, fmt=L.FMT_F32).startswith("k_code_to_dense_wide<Cube3,f32> tiles_per_group=37 grid=111")
     assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 16, fmt=L.FMT_F32).startswith("k_code_to_dense<Cube3,f32,TILE=64> grid=1024")
-    assert L.describe(L.OP_EXPAND, 3, 1 << 20, outputs=L.OUT_STATES | L.OUT_FLAGS).startswith("k_expand<Cube3,V=2> parts=1 grid=2048")
+    assert L.describe(L.OP_EXPAND, 3, 1 << 20, outputs=L.OUT_STATES | L.OUT_FLAGS).startswith("k_expand_stream<Cube3> grid=512")
+    assert L.describe(L.OP_EXPAND, 3, 1 << 20, outputs=L.OUT_STATES | L.OUT_FLAGS, variant=800).startswith("k_expand<Cube3,V=2> parts=1 grid=2048")
+    assert L.describe(L.OP_EXPAND, 3, 4096, outputs=L.OUT_STATES | L.OUT_FLAGS).startswith("k_expand<Cube3,V=1>")
     assert L.describe(L.OP_ADI, 3, 100000, 30, outputs=L.OUT_STATES | L.OUT_FLAGS).startswith("k_adi<Cube3,V=2> parts=1 segs=1 grid=196")
     assert L.describe(L.OP_ADI, 3, 100000, 30, outputs=L.OUT_CODE | L.OUT_FLAGS).startswith("k_adi<Cube3,V=2,code> parts=1 segs=3 grid=588")
     assert "segs=5 " in L.describe(L.OP_ADI, 3, 100000, 5, outputs=L.OUT_CODE, variant=9001001)       # clamped to the depth

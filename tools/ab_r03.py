@@ -147,6 +147,19 @@ def main():
                     emit(k=f"c2d_{name}", n=m, buf=bi, groups=-256, skew=0, us=t * 1e6, frac=(20 + bpc) * m / t / 8e12)
                     del oh
             del a, code
+    if "expandstream" in which:
+        m = 1 << 20
+        src = ops.alloc_states(m, 3, "cuda")
+        ops.fill_solved(src, m, 3)
+        ops.scramble(src, m, 3, 20, seed=5)
+        for rep in range(3):
+            o = ops.expand_buffers(m, 3, "cuda", children=True, codes=False)
+            pitch = o["children"].shape[-1]
+            for label, var in (("k_expand_2048_waves", 800), ("stream128", 100), ("stream192", 200), ("stream256", 300), ("stream384", 400), ("stream512", 500),
+                               ("stream768", 600), ("stream1024", 700), ("default", 0)):
+                t = timeit(lambda: ops.expand_children(src, m, 3, o["children"], o["child_solved"], pitch=pitch, variant=var), iters=20)
+                emit(k=f"expand_1M_{label}", rep=rep, us=t * 1e6, frac=(54 + 12 * 54 + 12) * m / t / 8e12, kernel=_lib.describe(_lib.OP_EXPAND, 3, m, outputs=_lib.OUT_STATES | _lib.OUT_FLAGS, variant=var))
+            del o
     if "adirep" in which:
         W, D = 100_000, 30
         for rep in range(3):

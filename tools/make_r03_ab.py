@@ -110,6 +110,11 @@ out["adi_code_store_shape"] = {
     "reading": "the wide shape is 25-35 % SLOWER (190-200 us against 146-157 us): not adopted, the code layout stays [slot][pitch]",
     "also": "a cheap necessary pre-test for the child flags (some face entirely home) cut the dynamic VALU work by ~20 % and changed nothing "
             "(r03s: 149-155 us / 170 us): the launch is bound by its store stream, not by VALU"}
+out["expand_streaming"] = {
+    "what": "expansion of 2^20 parents to 12 children + flags: 2048 short-lived waves (k_expand) against the streaming form with 128 .. 1024 persistent waves "
+            "(next group's rows prefetched under the current group's stores), three repeats",
+    "table_us": table(rows("r03x_expand.jsonl"), lambda r: r["k"], lambda r: f"rep{r['rep']}"),
+    "reading": "512 waves 113 us (0.83) against 116.4 us (0.80); 128 waves are too few (155 us), 384 do not divide the 2048 walk groups evenly (123 us)"}
 out["dense_window_form"] = {
     "what": "code -> dense as a memset-like WINDOW: passes of 960 threads (15 KiB of output) dealt round-robin to G workgroups, code bytes read straight from global "
             "memory (experiment build); against the 256-thread form and the wide form (112 / 128 groups), three buffers each, on a session whose allocations were "

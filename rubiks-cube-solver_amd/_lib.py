@@ -98,7 +98,18 @@ def init(device: torch.device):
     return idx
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # the current stream's handle without building a Stream object
+
+
 def stream_ptr(device=None):
+    """hipStream_t of torch's CURRENT stream on `device` as a void* (looked up per call: the library is stream-ordered)."""
+    if _raw_stream is not None:
+        if isinstance(device, str):
+            device = torch.device(device)
+        idx = device.index if isinstance(device, torch.device) else device if isinstance(device, int) else None
+        if idx is None:
+            idx = torch.cuda.current_device()
+        return ctypes.c_void_p(_raw_stream(idx))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

@@ -145,7 +145,7 @@ class CubeEnv:
     def _step_device(self, idx):
         f = self._facade()
         v = self._vec
-        rc = f[6](f[3], f[4], self.cube_size, idx, f[2], f[5], 1, ctypes.c_void_p(torch.cuda.current_stream(v.device).cuda_stream))
+        rc = f[6](f[3], f[4], self.cube_size, idx, f[2], f[5], 1, _lib.stream_ptr(v.device))
         if rc:
             _lib.check(rc)
         R, C = self.state_dim
@@ -160,7 +160,7 @@ class CubeEnv:
         acts = bytes(names.index(names[a]) for a in actions)        # same IndexError / TypeError as step()
         f = self._facade()
         v = self._vec
-        rc = f[8](f[3], f[4], self.cube_size, acts, len(acts), f[2], f[5], 1, ctypes.c_void_p(torch.cuda.current_stream(v.device).cuda_stream))
+        rc = f[8](f[3], f[4], self.cube_size, acts, len(acts), f[2], f[5], 1, _lib.stream_ptr(v.device))
         if rc:
             _lib.check(rc)
         R, C = self.state_dim
@@ -174,7 +174,7 @@ class CubeEnv:
         (own compact code bytes, child codes uint8 [A, SLOTS], child solved bool [A][, child one-hots uint8 [A, R, C]])."""
         f = self._facade()
         v = self._vec
-        rc = f[7](f[3], f[4], self.cube_size, f[2], f[5], int(dense), 1, ctypes.c_void_p(torch.cuda.current_stream(v.device).cuda_stream))
+        rc = f[7](f[3], f[4], self.cube_size, f[2], f[5], int(dense), 1, _lib.stream_ptr(v.device))
         if rc:
             _lib.check(rc)
         A, SL = self.action_dim, ops.N_SLOTS[self.cube_size]

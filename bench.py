@@ -267,6 +267,20 @@ def other_configs(torch, ops, _lib, dev, acts):
         dt = (time.perf_counter() - t0) / (len(seq) - 500)
         out["facade_batch1"] = {"CubeEnv.step_us": dt * 1e6, "steps_per_s": 1 / dt,
                                 "note": "reference: 24.6 us/step on one CPU core (SURVEY.md section 6); rc_facade_step, results via host-mapped memory"}
+        # BASELINE config 1's shape (plumbing): 2x2x2, batch 1, reset(seed, 20) then step() + solved flag, through the same facade
+        env2 = rc.make_env(torch.device("cpu"), 2)
+        t0 = time.perf_counter()
+        for sd in range(200):
+            env2.reset(seed=sd, scramble_count=20)
+        reset_us = (time.perf_counter() - t0) / 200 * 1e6
+        seq2 = np.random.default_rng(1).integers(0, 6, 3000)
+        for a_ in seq2[:300]:
+            env2.step(int(a_))
+        t0 = time.perf_counter()
+        for a_ in seq2[300:]:
+            _, _, solved2, _ = env2.step(int(a_))
+        out["facade_batch1"]["config1_2x2x2"] = {"reset_seed_k20_us": reset_us, "step_us": (time.perf_counter() - t0) / (len(seq2) - 300) * 1e6,
+                                                 "note": "2x2x2 values are unpinned (the reference ships no py222): plumbing only"}
     except Exception as e:
         out["facade_batch1"] = {"error": str(e)[:200]}
     return out

@@ -115,6 +115,13 @@ out["expand_streaming"] = {
             "(next group's rows prefetched under the current group's stores), three repeats",
     "table_us": table(rows("r03x_expand.jsonl"), lambda r: r["k"], lambda r: f"rep{r['rep']}"),
     "reading": "512 waves 113 us (0.83) against 116.4 us (0.80); 128 waves are too few (155 us), 384 do not divide the 2048 walk groups evenly (123 us)"}
+out["dense_fused_wide_pipelined"] = {
+    "what": "second attempt at a FUSED wide dense kernel (experiment build): every wave issues the 54 row loads of its next tile, all 960 threads sweep the current "
+            "round's 15 tiles out of one LDS buffer, then every wave finishes its next tile into the other buffer (156 KB of LDS); group counts 80 .. 256 against "
+            "the 256-thread form, three buffers each; outputs verified equal",
+    "table_frac": table(rows("r03A_fused.jsonl"), lambda r: f"{r['k']}_buf{r['buf']}", lambda r: r["form"], "frac"),
+    "reading": "bf16 0.63-0.70 against 0.72-0.73, u8 0.54-0.75 against 0.81-0.82, f32 0.77 against 0.74 (112 groups): not shipped; the fused launch keeps the "
+               "256-thread form, whose ~1000 concurrent producers hide the state traffic better than ~110 wide workgroups can"}
 out["dense_window_form"] = {
     "what": "code -> dense as a memset-like WINDOW: passes of 960 threads (15 KiB of output) dealt round-robin to G workgroups, code bytes read straight from global "
             "memory (experiment build); against the 256-thread form and the wide form (112 / 128 groups), three buffers each, on a session whose allocations were "

@@ -1079,7 +1079,7 @@ int check_fmt(void *onehot, int fmt, int64_t code_pitch, int64_t n, int *sh_code
 struct Geometry { int v, parts, segs; };
 constexpr int64_t kExpandStreamGrid = 512;   // 1M parents: 113 us (0.83) with 512 waves, 114 (256), 115 (1024), 116.4 us for 2048 short-lived waves
 constexpr double kReplayCostCodes = 0.2, kReplayCostStickers = 0.35;   // replayed depth / emitted depth (RNG + move against everything)
-Geometry pick_geometry(int64_t n, int A, int variant, bool stickers_out, int64_t out_bytes, bool codes = false) {
+Geometry pick_geometry(int64_t n, int A, int variant, bool stickers_out, int64_t out_bytes) {
     const int fv = variant % 10, fp = (variant / 1000) % 100;
     const bool stream = stickers_out && out_bytes >= ((int64_t)256 << 20);
     const int64_t want = stream ? 96 : stickers_out ? 2048 : 700;
@@ -1099,7 +1099,7 @@ Geometry pick_geometry(int64_t n, int A, int variant, bool stickers_out, int64_t
 // 2 segments (782 waves) 146-160 us, round 2's 4 walks per lane x 2 parts 162-166 us; more segments lose to the replayed
 // moves.  Rule: about 600 waves; wide packs once that still leaves >= 2 segments' worth of groups.
 Geometry pick_geometry_adi(int64_t n, int A, int variant, bool stickers_out, int64_t out_bytes, bool codes) {
-    Geometry g = pick_geometry(n, A, variant, stickers_out, out_bytes, codes);
+    Geometry g = pick_geometry(n, A, variant, stickers_out, out_bytes);
     if (codes && !stickers_out) {
         const int fv = variant % 10, fp = (variant / 1000) % 100;
         g.v = fv == 1 || fv == 2 ? fv : (n >= 64 * kWave * 8 ? 2 : 1);
@@ -1353,7 +1353,7 @@ int rc_expand_children_ex(const uint8_t *in, int64_t n, int64_t pitch_in, int cu
     if (n == 0) return RC_OK;
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
-        const Geometry geo = pick_geometry(n, T::A, variant, children != nullptr, n * T::S * T::A, child_code != nullptr);
+        const Geometry geo = pick_geometry(n, T::A, variant, children != nullptr, n * T::S * T::A);
         ExpandArgs a{in, n, pitch_in, children, child_solved, child_code, pitch_out, n <= pitch_out ? 1 : (n + pitch_out - 1) / pitch_out,
                      geo.parts, sh_in, sh_out};
         hipStream_t st = S(stream);
@@ -1539,7 +1539,7 @@ int rc_describe_dispatch(int op, int cube_size, int64_t n, int depth, unsigned o
             return RC_OK;
         }
         if (op == RC_OP_EXPAND) {
-            const Geometry geo = pick_geometry(n, T::A, variant, states, n * T::S * T::A, code);
+            const Geometry geo = pick_geometry(n, T::A, variant, states, n * T::S * T::A);
             if (const int64_t grid = expand_stream_grid(n, states, code, variant)) {
                 const int64_t groups = (n + 511) / 512;
                 snprintf(buf, buflen, "k_expand_stream<%s> grid=%lld block=64", cube, (long long)(grid < groups ? grid : groups));

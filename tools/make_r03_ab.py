@@ -122,6 +122,11 @@ out["dense_fused_wide_pipelined"] = {
     "table_frac": table(rows("r03A_fused.jsonl"), lambda r: f"{r['k']}_buf{r['buf']}", lambda r: r["form"], "frac"),
     "reading": "bf16 0.63-0.70 against 0.72-0.73, u8 0.54-0.75 against 0.81-0.82, f32 0.77 against 0.74 (112 groups): not shipped; the fused launch keeps the "
                "256-thread form, whose ~1000 concurrent producers hide the state traffic better than ~110 wide workgroups can"}
+out["dense_fused_contiguous_ranges"] = {
+    "what": "the shipped 256-thread fused step + dense kernel with CONTIGUOUS tile ranges per workgroup and 128 .. 3072 workgroups (experiment build) against its "
+            "shipped strided form (groups 0), three buffers each, outputs verified equal",
+    "table_frac": table(rows("r03D_fc.jsonl"), lambda r: f"{r['k']}_buf{r['buf']}", lambda r: str(r["groups"]), "frac"),
+    "reading": "no group count beats the shipped form (bf16 0.57-0.73 against 0.73-0.74, f32 0.60-0.69 against 0.70, u8 0.42-0.79 against 0.80-0.82)"}
 out["dense_window_form"] = {
     "what": "code -> dense as a memset-like WINDOW: passes of 960 threads (15 KiB of output) dealt round-robin to G workgroups, code bytes read straight from global "
             "memory (experiment build); against the 256-thread form and the wide form (112 / 128 groups), three buffers each, on a session whose allocations were "

@@ -90,6 +90,14 @@ out["dense_wide_groups"] = {
     "table_frac": table(rows("r03m_wide.jsonl"), lambda r: f"{r['k']}_buf{r['buf']}", lambda r: str(r["groups"]), "frac"),
     "reading": "fused: the wide form loses for every format and group count (bf16 0.62-0.74 against 0.74-0.76): ~110 workgroups funnel the state traffic and the dense "
                "stream stalls while they produce -- not shipped.  code -> dense: wide 112 wins on this box too (bf16 0.77-0.81 against 0.68-0.70)"}
+out["adi_store_wave"] = {
+    "what": "code-emitting ADI as a store-wave kernel (experiment build, parity-green): workgroup = 3 compute waves (one per depth segment, families handed over "
+            "through 153 KB of LDS, one barrier per emitted depth) + 1 store wave issuing all code rows; variant 100 = store wave, 900 = the shipped waves per segment; "
+            "walks x depth, us per launch (host clock around 3 launches)",
+    "rows": {"512x3": [39.4, 16.3], "512x30": [104.6, 38.5], "5120x30": [106.9, 41.4], "20000x30": [106.8, 52.6], "100000x3": [29.1, 25.7], "100000x30": [166.7, 155.0]},
+    "columns": ["store_wave_us", "shipped_us"],
+    "reading": "slower at every size: ~200 storing waves with at most 63 stores of 512 B in flight each cap the stream at 4.9 TB/s, and small batches pay the "
+               "lock-step barriers; not shipped"}
 t = collections.OrderedDict()
 for r in rows("r03q_skew.jsonl"):
     t.setdefault(f"{r['k']}_n{r['n']}_buf{r['buf']}", collections.OrderedDict())[f"g{r['groups']}_skew{r['skew']}"] = round(r["frac"], 3)

@@ -1404,9 +1404,9 @@ int rc_adi_generate(uint64_t seed, uint64_t stream_id, int64_t walk_offset, int6
 int rc_adi_targets(const float *child_value, const uint8_t *child_solved, const float *parent_value, const double *weight, int64_t n,
                    int64_t pitch, int cube_size, float *target_value, int32_t *target_policy, double *error, void *stream) {
     RC_NEED_INIT();
+    if (n == 0) return RC_OK;                                  // nothing to assemble: empty outputs may be null pointers
     if (!child_value || !child_solved || !target_value || !target_policy || n < 0 || pitch < n) return fail(RC_EINVAL, "rc_adi_targets: bad arguments%s");
     if (error && (!parent_value || !weight)) return fail(RC_EINVAL, "rc_adi_targets: error needs parent_value and weight%s");
-    if (n == 0) return RC_OK;
     const int64_t blocks = (n + 255) / 256;
     RC_GRID(blocks);
     const dim3 g((unsigned)blocks), b(256);

@@ -493,3 +493,39 @@ def test_legacy_numpy_rng_on_device(ops, L, golden, cs):
         assert (buf[:30, :len(g["seeds"])].cpu().numpy().T == g["actions"][:, 29, :]).all()
     with pytest.raises(ValueError):
         ops.legacy_scramble_actions(torch.tensor([-1]), cs, 3, device="cuda")
+
+
+def test_empty_batches_are_no_ops(ops, L):
+    """n = 0 (and depth = 0) through every batched entry point: RC_OK, nothing launched, nothing written (the reference's loops
+    over zero cubes / zero scramble moves do nothing either: cube_env.py:177-194 with sample_cube_count = 0)."""
+    st = ops.alloc_states(256, 3, "cuda")
+    st.fill_(9)
+    acts = torch.zeros(256, dtype=torch.uint8, device="cuda")
+    done = torch.full((256,), 9, dtype=torch.uint8, device="cuda")
+    rew = torch.full((256,), 9.0, dtype=torch.float32, device="cuda")
+    code = ops.alloc_code(256, 3, "cuda").fill_(9)
+    oh = torch.full((256, 20, 24), 9, dtype=torch.float32, device="cuda")
+    ops.fill_solved(st, 0, 3)
+    ops.apply_moves(st, st, acts, 0, 3, rew, done, code, L.FMT_CODE)
+    ops.apply_moves(st, st, acts, 0, 3, rew, done, oh, L.FMT_F32)
+    ops.scramble(st, 0, 3, 5, seed=1)
+    ops.scramble(st, 256, 3, 0, seed=1)                              # zero moves: the states stay as they are
+    ops.is_solved(st, 0, 3, done, rew)
+    ops.encode(st, 0, 3, code, L.FMT_CODE)
+    ops.onehot_from_code(code, 0, 3, oh)
+    ex = ops.expand_buffers(256, 3, "cuda", children=True, codes=True)
+    for t in ex.values():
+        t.fill_(9)
+    ops.expand_children(st, 0, 3, ex["children"], ex["child_solved"], ex["child_code"], pitch=ex["children"].shape[-1])
+    pt, bufs = ops.adi_buffers(256, 4, 3, "cuda", parents=True, children=True, parent_code=True, child_code=True)
+    for t in bufs.values():
+        t.fill_(9)
+    ops.adi_generate(0, 4, 3, pt, "cuda", seed=1, **bufs)
+    ops.adi_generate(256, 0, 3, pt, "cuda", seed=1, **{k: v[:0] for k, v in bufs.items()})
+    torch.cuda.synchronize()
+    for t in (st, done, code, *ex.values(), *bufs.values()):
+        assert bool((t == 9).all())
+    assert bool((rew == 9.0).all()) and bool((oh == 9.0).all())
+    tv, tp, err = ops.adi_targets(torch.zeros((12, 256), device="cuda"), torch.zeros((12, 256), dtype=torch.uint8, device="cuda"), 0, 3)
+    assert tv.numel() == 0 and tp.numel() == 0 and err is None
+    assert L.read_status() == 0

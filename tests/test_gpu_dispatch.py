@@ -394,3 +394,37 @@ def test_randomised_ragged_sizes_all_kernels(ops, L, oracle):
         if cs == 3:
             assert (oh.float().argmax(-1).cpu().numpy() == exp_code).all(), tag
     assert L.read_status() == 0
+
+
+def test_ninety_million_cubes_cross_the_4gib_line(ops, L, oracle):
+    """Maximum-size edge: 90 000 001 cubes = 4.86 GB per state buffer, so tile offsets pass 2^32 bytes (cube 79.5 M).  Device-drawn
+    3-move scrambles are compared with the oracle on three windows (start, around the 4-GiB line, the ragged end), a move followed
+    by its inverse restores every byte, and the fused compact code of the windows equals the oracle's (py333.py:220-246)."""
+    cs, n, depth = 3, 90_000_001, 3
+    st = ops.alloc_states(n, cs, "cuda")
+    assert st.numel() > (1 << 32)
+    done = torch.empty(n, dtype=torch.uint8, device="cuda")
+    ops.fill_solved(st, n, cs)
+    ops.is_solved(st, n, cs, done)
+    assert int(done.sum()) == n
+    ops.scramble(st, n, cs, depth, seed=77, stream_id=3)
+    pitch = st.shape[-1]
+    line = ((1 << 32) // (54 * pitch)) * pitch                       # first cube of the tile that straddles byte 2^32
+    windows = [(0, 70_000), (line - 40_000, 80_000), (n - 70_001, 70_001)]
+    aos = lambda t, w0, m: ops.to_aos(t[w0 // pitch:(w0 + m - 1) // pitch + 1], (w0 % pitch) + m)[w0 % pitch:].cpu().numpy()
+    expect = {}
+    for w0, m in windows:
+        exp = oracle.adi(cs, m, depth, seed=77, stream=3, walk0=w0, threads=8, want_children=False)
+        expect[w0] = (exp["parents"][:, -1], exp["parent_code"][:, -1])
+        assert (aos(st, w0, m) == expect[w0][0]).all(), w0
+    g = torch.Generator(device="cuda").manual_seed(5)
+    acts = torch.randint(0, 12, (n,), generator=g, device="cuda", dtype=torch.uint8)
+    out = torch.empty_like(st)
+    code = ops.alloc_code(n, cs, "cuda")
+    ops.apply_moves(st, out, acts, n, cs, None, done)
+    ops.apply_moves(out, out, acts ^ 1, n, cs, None, done, code, L.FMT_CODE)          # X' undoes X, in place, with the fused code
+    flat = lambda t: t.permute(0, 2, 1).reshape(-1, t.shape[1])[:n]                      # ignore the pad columns of the last tile
+    assert torch.equal(flat(out), flat(st))
+    for w0, m in windows:
+        assert (aos(code, w0, m) == expect[w0][1]).all(), w0
+    assert L.read_status() == 0

@@ -428,3 +428,42 @@ def test_ninety_million_cubes_cross_the_4gib_line(ops, L, oracle):
     for w0, m in windows:
         assert (aos(code, w0, m) == expect[w0][1]).all(), w0
     assert L.read_status() == 0
+
+
+def test_outputs_beyond_4gib_adi_and_expansion(ops, L, oracle):
+    """Write-once output streams larger than 4 GiB: ADI 230 000 walks x 30 (children 4.47 GB) and the expansion of 2^23 parents
+    (children 5.4 GB).  Windows at the start and at the very end of the streams against the oracle (64-bit base offsets of the per-
+    child descriptors; cube_env.py:177-194,212-236)."""
+    cs, W, D = 3, 230_000, 30
+    pt, bufs = ops.adi_buffers(W, D, cs, "cuda", parents=True, children=True)
+    assert bufs["children"].numel() > (1 << 32)
+    ops.adi_generate(W, D, cs, pt, "cuda", seed=31, stream_id=2, **bufs)
+    for w0, m in ((0, 16384), (W - 16384 - 176, 16384 + 176)):        # first tile; the last (ragged) tiles
+        exp = oracle.adi(cs, m, D, seed=31, stream=2, walk0=w0, threads=8)
+        t0, t1 = w0 // pt, (w0 + m - 1) // pt
+        for d in (0, D - 1):
+            for a in (0, 11):
+                got = ops.to_aos(bufs["children"][d, a, t0:t1 + 1], (w0 - t0 * pt) + m)[w0 - t0 * pt:].cpu().numpy()
+                assert (got == exp["children"][:, d, a]).all(), (w0, d, a)
+            assert (bufs["child_solved"][d, :, w0:w0 + m].cpu().numpy().T == exp["child_solved"][:, d]).all(), (w0, d)
+        assert (bufs["actions_out"][:, w0:w0 + m].cpu().numpy().T == exp["actions"]).all(), w0
+    del bufs
+    torch.cuda.empty_cache()
+    n = (1 << 23) + 5
+    st = ops.alloc_states(n, cs, "cuda")
+    ops.fill_solved(st, n, cs)
+    ops.scramble(st, n, cs, 6, seed=8, stream_id=1)
+    ex = ops.expand_buffers(n, cs, "cuda", children=True, codes=False)
+    assert ex["children"].numel() > (1 << 32)
+    ops.expand_children(st, n, cs, ex["children"], ex["child_solved"], pitch=ex["children"].shape[-1])
+    p = st.shape[-1]
+    for w0, m in ((0, 40_000), (n - 40_000, 40_000)):
+        t0, t1 = w0 // p, (w0 + m - 1) // p
+        parents = ops.to_aos(st[t0:t1 + 1], (w0 - t0 * p) + m)[w0 - t0 * p:].cpu().numpy()
+        ch, _, cso = oracle.expand(cs, parents, threads=8)
+        for a in (0, 5, 11):
+            got = ops.to_aos(ex["children"][a, t0:t1 + 1], (w0 - t0 * p) + m)[w0 - t0 * p:].cpu().numpy()
+            assert (got == ch[:, a]).all(), (w0, a)
+        assert (ex["child_solved"][:, w0:w0 + m].cpu().numpy().T == cso).all(), w0
+    assert "k_expand_stream" in L.describe(L.OP_EXPAND, cs, n, outputs=L.OUT_STATES | L.OUT_FLAGS)
+    assert L.read_status() == 0

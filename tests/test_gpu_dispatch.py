@@ -467,3 +467,28 @@ def test_outputs_beyond_4gib_adi_and_expansion(ops, L, oracle):
         assert (ex["child_solved"][:, w0:w0 + m].cpu().numpy().T == cso).all(), w0
     assert "k_expand_stream" in L.describe(L.OP_EXPAND, cs, n, outputs=L.OUT_STATES | L.OUT_FLAGS)
     assert L.read_status() == 0
+
+
+def test_dense_outputs_beyond_4gib(ops, L):
+    """Dense one-hot streams larger than 4 GiB: 2^22 cubes as float32 (8 GB) through the wide code -> dense writer and through the
+    fused step; every cube's arg-max against the compact code of the same states, one 1 per row (py333.py:235-246)."""
+    cs, n = 3, 1 << 22
+    st = ops.alloc_states(n, cs, "cuda")
+    ops.fill_solved(st, n, cs)
+    ops.scramble(st, n, cs, 9, seed=4)
+    code = ops.alloc_code(n, cs, "cuda")
+    ops.encode(st, n, cs, code, L.FMT_CODE)
+    want = ops.to_aos(code, n)
+    oh = torch.empty((n, 20, 24), dtype=torch.float32, device="cuda")
+    assert oh.numel() * 4 > (1 << 32)
+    for how in ("code_to_dense", "fused"):
+        oh.fill_(3.0)
+        if how == "fused":
+            ops.apply_moves(st, st, torch.full((n,), 12, dtype=torch.uint8, device="cuda"), n, cs, None, None, oh, L.FMT_F32)   # the no-op action
+        else:
+            ops.onehot_from_code(code, n, cs, oh)
+        for lo_ in range(0, n, 1 << 20):                                  # chunked: keeps the temporaries small
+            blk = oh[lo_:lo_ + (1 << 20)]
+            assert torch.equal(blk.argmax(-1).to(torch.uint8), want[lo_:lo_ + (1 << 20)]), (how, lo_)
+            assert float(blk.sum()) == 20.0 * blk.shape[0] and float(blk.max()) == 1.0, (how, lo_)
+    assert L.read_status() == 0

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: cube-move steps/s, 3x3x3, batch 4M per GPU (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--cubes-per-gpu C] [--no-cpu] [--no-configs]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--cubes-per-gpu C] [--no-cpu] [--no-configs] [--force-dist] [--backend nccl|gloo]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W [--cubes-per-gpu 1048576]
 
@@ -9,18 +9,23 @@ One bench "step" = one pass of the hot path over one batch: ONE rc_apply_moves l
 C cubes per GPU (each by its own random face turn) and writes their solved flags, ping-ponging two
 HBM-resident state buffers.  C defaults to 2^22 (the metric's batch: working set 453 MB > the 256 MB Infinity
 Cache); --cubes-per-gpu 1048576 is BASELINE config 4's shape (1M cubes per GPU x N GPUs).
-Inputs are resident in HBM before the timed region.  value = cubes * K * N / max-over-ranks time.
+Inputs are resident in HBM before the timed region.  value = cubes * K * N / max-over-ranks time of the K timed steps.
 Every rank owns its own batch and RNG stream (stream_id = rank); there is no collective on the
-env path ("scaling": "weak").  One JSON line is printed by rank 0; with N > 1 it carries `per_gpu` (each rank's stream_id,
-rate and a sha256 of its first 65536 scrambled cubes, which the tests compare with the oracle's (seed, rank) stream).
+env path ("scaling": "weak").  One JSON line is printed by rank 0; in the distributed branch it carries `per_gpu` (each rank's
+stream_id, rate and a sha256 of its first 65536 scrambled cubes, which the tests compare with the oracle's (seed, rank) stream).
+The distributed branch (process group, barrier, all_gather, MAX over ranks) runs for N > 1, under a launcher at N = 1
+(torch.distributed.run --nproc-per-node 1) and with --force-dist, so the code the 2/4/8-GPU runs execute can be exercised on one GPU.
 
-The line also carries "configs" (rank 0, every N): the other BASELINE.json workloads, each timed OUTSIDE the headline's timed
-region with HIP events on the launch stream and with a roofline sub-record of its own (kernel = what the library's own
-dispatch reports, algorithmic bytes per launch, achieved GB/s, fraction of the 8 TB/s HBM peak): config 2 (1M cubes,
-move + reward + done), the 4M step in place, with the reward, with the fused compact code, the 16M-cube step whose 1.8 GB
-ping-pong defeats the Infinity Cache (the HBM-only point: roofline.frac_hbm_only), the fused dense one-hot (f32 / bf16), code -> dense (f32 / bf16),
-config 3 (ADI 100k walks x 30, 715 B per (walk, depth)), the 1M-parent expansion, config 5 (us per MCTS step, eager and
-as a hipGraph) and the batch-1 facade latency.  --no-configs skips them.
+roofline.launch_us is the MEDIAN of R >= 7 further batches of K launches, each bracketed by HIP events on the launch stream, run
+right after the timed region (launch_us_min / _max beside it, launch_us_timed_region = the K timed steps themselves).
+
+roofline.per_config and "configs" (rank 0, after the process group is gone): the other BASELINE.json workloads, each timed OUTSIDE
+the headline's timed region with HIP events on the launch stream (median of 3 batches) and with a roofline record of its own
+(kernel = what the library's own dispatch reports, algorithmic bytes per launch, achieved GB/s, fraction of the 8 TB/s HBM peak):
+config 2 (1M cubes, move + reward + done), the 4M step in place, with the reward, with the fused compact code, the 16M-cube step
+whose 1.8 GB ping-pong defeats the Infinity Cache (the HBM-only point: roofline.frac_hbm_only), the fused dense one-hot (f32 /
+bf16), code -> dense (f32 / bf16), config 3 (ADI 100k walks x 30, 715 B per (walk, depth)), the 1M-parent expansion, config 5
+(us per MCTS step, eager and as a hipGraph) and the batch-1 facade latency.  --no-configs skips them.
 """
 import argparse
 import json
@@ -35,6 +40,7 @@ N_CUBES = 1 << 22
 CUBE = 3
 BYTES_PER_STEP = 54 + 54 + 1 + 1  # stickers R + W, action, done flag
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBPS = 6300.0      # same guide: "8 TB/s peak (spec); about 6.3 TB/s achievable"
 
 
 def cpu_share():
@@ -139,21 +145,25 @@ def other_configs(torch, ops, _lib, dev, acts):
     D = _lib.describe
     ST, CODE, FLAGS, REW, INPL = _lib.OUT_STATES | _lib.OUT_DONE, _lib.OUT_CODE, _lib.OUT_FLAGS, _lib.OUT_REWARD, _lib.OUT_INPLACE
 
-    def timed(fn, iters, warm=5):
+    def timed(fn, iters, warm=5, reps=3):
+        """seconds per launch: the median of `reps` event-timed batches of `iters` launches"""
         for _ in range(warm):
             fn()
         torch.cuda.synchronize()
-        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s0.record()
-        for _ in range(iters):
-            fn()
-        s1.record()
-        torch.cuda.synchronize()
-        return s0.elapsed_time(s1) / iters * 1e-3
+        vals = []
+        for _ in range(reps):
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            for _ in range(iters):
+                fn()
+            s1.record()
+            torch.cuda.synchronize()
+            vals.append(s0.elapsed_time(s1) / iters * 1e-3)
+        return sorted(vals)[len(vals) // 2]
 
-    def rec(name, kernel, units, unit_name, bytes_per_unit, t, note=None, bound="hbm"):
+    def rec(short, name, kernel, units, unit_name, bytes_per_unit, t, note=None, bound="hbm"):
         achieved = bytes_per_unit * units / t / 1e9
-        r = {"config": name, "kernel": kernel, "launch_us": t * 1e6, "value": units / t, "unit": f"{unit_name}/s",
+        r = {"short": short, "config": name, "kernel": kernel, "launch_us": t * 1e6, "value": units / t, "unit": f"{unit_name}/s",
              "roofline": {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                           "algorithmic_bytes_per_launch": bytes_per_unit * units, "bytes_per_unit": bytes_per_unit}}
         if note:
@@ -172,7 +182,7 @@ def other_configs(torch, ops, _lib, dev, acts):
     ops.scramble(a1, m, CUBE, 20, seed=1234)
     pp = [a1, b1]
     t = timed(lambda: (ops.apply_moves(pp[0], pp[1], acts, m, CUBE, rew, done), pp.reverse()), 200)
-    rec("config 2: 3x3x3 batch 1M, apply_move + reward + done", D(_lib.OP_STEP, CUBE, m, outputs=ST | REW), m, "steps", 114, t,
+    rec("cfg2 1M step+reward", "config 2: 3x3x3 batch 1M, apply_move + reward + done", D(_lib.OP_STEP, CUBE, m, outputs=ST | REW), m, "steps", 114, t,
         "working set 113 MB: served from the 256 MB Infinity Cache, not HBM")
     # the metric's batch: in place, with the reward, with the fused compact one-hot code
     a4, b4 = ops.alloc_states(n, CUBE, dev), ops.alloc_states(n, CUBE, dev)
@@ -180,13 +190,13 @@ def other_configs(torch, ops, _lib, dev, acts):
     ops.scramble(a4, n, CUBE, 20, seed=1234)
     p4 = [a4, b4]
     t = timed(lambda: ops.apply_moves(a4, a4, acts, n, CUBE, None, done), 50)
-    rec("3x3x3 batch 4M, apply_move + done IN PLACE (what VecCubeEnv.step launches; 226 MB working set)", D(_lib.OP_STEP, CUBE, n, outputs=ST | INPL),
+    rec("4M step in place", "3x3x3 batch 4M, apply_move + done IN PLACE (what VecCubeEnv.step launches; 226 MB working set)", D(_lib.OP_STEP, CUBE, n, outputs=ST | INPL),
         n, "steps", 110, t, "one buffer read and rewritten: the working set fits the Infinity Cache")
     t = timed(lambda: (ops.apply_moves(p4[0], p4[1], acts, n, CUBE, rew, done), p4.reverse()), 50)
-    rec("3x3x3 batch 4M, apply_move + reward + done", D(_lib.OP_STEP, CUBE, n, outputs=ST | REW), n, "steps", 114, t)
+    rec("4M step+reward", "3x3x3 batch 4M, apply_move + reward + done", D(_lib.OP_STEP, CUBE, n, outputs=ST | REW), n, "steps", 114, t)
     code = ops.alloc_code(n, CUBE, dev)
     t = timed(lambda: (ops.apply_moves(p4[0], p4[1], acts, n, CUBE, rew, done, code, _lib.FMT_CODE), p4.reverse()), 50)
-    rec("3x3x3 batch 4M, apply_move + reward + done + fused compact one-hot code (20 B)", D(_lib.OP_STEP, CUBE, n, outputs=ST | REW | CODE, fmt=_lib.FMT_CODE),
+    rec("4M step+reward+code", "3x3x3 batch 4M, apply_move + reward + done + fused compact one-hot code (20 B)", D(_lib.OP_STEP, CUBE, n, outputs=ST | REW | CODE, fmt=_lib.FMT_CODE),
         n, "steps", 134, t)
     del code, a4, b4, p4
     # the HBM-only point: 2^24 cubes, 1.8 GB ping-pong -- nothing of it survives in the 256 MB Infinity Cache between launches
@@ -198,7 +208,7 @@ def other_configs(torch, ops, _lib, dev, acts):
     done16 = torch.empty(n16, dtype=torch.uint8, device=dev)
     p16 = [a16, b16]
     t = timed(lambda: (ops.apply_moves(p16[0], p16[1], acts16, n16, CUBE, None, done16), p16.reverse()), 20, 3)
-    hbm_only = rec("3x3x3 batch 16M, apply_move + done, nothing cached (1.8 GB ping-pong: the HBM-only point)", D(_lib.OP_STEP, CUBE, n16, outputs=ST),
+    hbm_only = rec("16M step (HBM only)", "3x3x3 batch 16M, apply_move + done, nothing cached (1.8 GB ping-pong: the HBM-only point)", D(_lib.OP_STEP, CUBE, n16, outputs=ST),
                    n16, "steps", 110, t, "inputs and outputs streamed (nt / sc0 sc1 nt): every byte comes from and goes to HBM")
     del a16, b16, p16, acts16, done16
     torch.cuda.empty_cache()
@@ -209,13 +219,13 @@ def other_configs(torch, ops, _lib, dev, acts):
     acts2 = acts % 6
     p2 = [a2, b2]
     t = timed(lambda: (ops.apply_moves(p2[0], p2[1], acts2, n, 2, None, done), p2.reverse()), 100)
-    rec("2x2x2 batch 4M, apply_move + done (201 MB ping-pong: Infinity-Cache resident)", D(_lib.OP_STEP, 2, n, outputs=ST), n, "steps", 50, t)
+    rec("2x2x2 4M step", "2x2x2 batch 4M, apply_move + done (201 MB ping-pong: Infinity-Cache resident)", D(_lib.OP_STEP, 2, n, outputs=ST), n, "steps", 50, t)
     del a2, b2, p2, acts2
     # fused dense one-hot in the layout model.py consumes
     for dt, fmt, name, bpc in ((torch.float32, _lib.FMT_F32, "f32", 1920), (torch.bfloat16, _lib.FMT_BF16, "bf16", 960)):
         oh = torch.empty((m, 20, 24), dtype=dt, device=dev)
         t = timed(lambda: ops.apply_moves(a1, b1, acts, m, CUBE, rew, done, oh, fmt), 10, 2)
-        rec(f"3x3x3 batch 1M, apply_move + reward + done + fused dense {name} one-hot [N,20,24]", D(_lib.OP_STEP, CUBE, m, outputs=ST | REW, fmt=fmt), m, "steps",
+        rec(f"1M step+dense {name}", f"3x3x3 batch 1M, apply_move + reward + done + fused dense {name} one-hot [N,20,24]", D(_lib.OP_STEP, CUBE, m, outputs=ST | REW, fmt=fmt), m, "steps",
             114 + bpc, t)
         del oh
     # compact code -> dense one-hot: what adi_samples, the replay sink and the lockstep search launch (the wide writer)
@@ -224,25 +234,25 @@ def other_configs(torch, ops, _lib, dev, acts):
     for dt, fmt, name, bpc in ((torch.float32, _lib.FMT_F32, "f32", 1920), (torch.bfloat16, _lib.FMT_BF16, "bf16", 960)):
         oh = torch.empty((m, 20, 24), dtype=dt, device=dev)
         t = timed(lambda: ops.onehot_from_code(code1, m, CUBE, oh), 10, 2)
-        rec(f"3x3x3 batch 1M, compact code -> dense {name} one-hot [N,20,24] (rc_onehot_from_code)", D(_lib.OP_CODE_TO_DENSE, CUBE, m, fmt=fmt), m, "cubes",
+        rec(f"1M code->dense {name}", f"3x3x3 batch 1M, compact code -> dense {name} one-hot [N,20,24] (rc_onehot_from_code)", D(_lib.OP_CODE_TO_DENSE, CUBE, m, fmt=fmt), m, "cubes",
             20 + bpc, t)
         del oh
     del code1
     # 1M-parent expansion (the MCTS / ADI child loop at scale)
     ex = ops.expand_buffers(m, CUBE, dev, children=True, codes=False)
     t = timed(lambda: ops.expand_children(a1, m, CUBE, ex["children"], ex["child_solved"], pitch=ex["children"].shape[-1]), 30)
-    rec("3x3x3 expansion of 1M parents to all 12 children + solved flags", D(_lib.OP_EXPAND, CUBE, m, outputs=ST | FLAGS), m, "parents", 54 + 12 * 54 + 12, t)
+    rec("1M expansion", "3x3x3 expansion of 1M parents to all 12 children + solved flags", D(_lib.OP_EXPAND, CUBE, m, outputs=ST | FLAGS), m, "parents", 54 + 12 * 54 + 12, t)
     del ex, a1, b1, pp
     # config 3: ADI data generation
     W, DEPTH = 100_000, 30
     pt, ab = ops.adi_buffers(W, DEPTH, CUBE, dev, parents=True, children=True)
     t = timed(lambda: ops.adi_generate(W, DEPTH, CUBE, pt, dev, seed=2024, **ab), 10, 3)
-    rec("config 3: ADI 100k walks x depth 30, parents + 12 children + flags + actions", D(_lib.OP_ADI, CUBE, W, DEPTH, outputs=ST | FLAGS), W * DEPTH, "walk-depths", 715, t,
+    rec("cfg3 ADI 100k x 30", "config 3: ADI 100k walks x depth 30, parents + 12 children + flags + actions", D(_lib.OP_ADI, CUBE, W, DEPTH, outputs=ST | FLAGS), W * DEPTH, "walk-depths", 715, t,
         f"{13 * W * DEPTH / t:.4g} cube-move steps/s; output tiles of {pt} walks; 0 bytes read")
     del ab
     pt, ab = ops.adi_buffers(W, DEPTH, CUBE, dev, **ADI_CODE_OUTPUTS)
     t = timed(lambda: ops.adi_generate(W, DEPTH, CUBE, pt, dev, seed=2024, **ab), 10, 3)
-    rec("ADI 100k x 30 with compact codes instead of child stickers (parent stickers + 13 codes + flags + actions)", D(_lib.OP_ADI, CUBE, W, DEPTH, outputs=CODE | FLAGS),
+    rec("ADI 100k x 30 codes", "ADI 100k x 30 with compact codes instead of child stickers (parent stickers + 13 codes + flags + actions)", D(_lib.OP_ADI, CUBE, W, DEPTH, outputs=CODE | FLAGS),
         W * DEPTH, "walk-depths", 54 + 1 + 12 + 13 * 20, t, f"output tiles of {pt} walks")
     del ab
     torch.cuda.empty_cache()
@@ -291,6 +301,21 @@ SAMPLE_CUBES = 1 << 16      # per-rank sample whose sha256 the N>1 line carries 
 SCRAMBLE_SEED, SCRAMBLE_DEPTH = 1234, 20
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return str(sock.getsockname()[1])
+
+
+def per_config_summary(configs):
+    """Compact per-config table for the `roofline` object: name, kernel, launch time, algorithmic bytes per launch, fraction of the
+    8 TB/s peak -- frac = bytes / (launch_us * 1e-6) / 8e12, recomputable from the row alone."""
+    return [{"name": r["short"], "kernel": r["kernel"].split(" grid=")[0], "launch_us": round(r["launch_us"], 2),
+             "bytes": r["roofline"]["algorithmic_bytes_per_launch"], "frac": round(r["roofline"]["frac"], 4)}
+            for r in configs["records"]]
+
+
 def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before anything initialises the HIP runtime (RCCL / IPC, N > 1)
     ap = argparse.ArgumentParser()
@@ -302,7 +327,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs (timed outside the headline region)")
     ap.add_argument("--extras", action="store_true", help="(kept for compatibility: the configs are on by default)")
-    ap.add_argument("--backend", default="nccl", help="process-group backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--backend", default="nccl", help="process-group backend of the distributed branch (nccl = RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the distributed branch (process group, barrier, all_gather, MAX over ranks) even at world size 1")
+    ap.add_argument("--batches", type=int, default=0, help="event-timed batches of --steps launches after the timed region (0 = max(7, 140 / steps))")
     args = ap.parse_args()
     if args.cubes_per_gpu < 1:
         sys.exit("--cubes-per-gpu must be positive")
@@ -319,11 +347,21 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    # the distributed branch also runs at world size 1 when asked to (--force-dist) or when a launcher set the rendezvous up
+    # (torch.distributed.run --nproc-per-node 1): the same code the N = 2/4/8 runs execute, on the one GPU a builder has
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ and "MASTER_PORT" in os.environ
+    use_dist = world > 1 or args.force_dist or launched
+    if use_dist and args.backend == "nccl" and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
+        # checked before anything touches the GPU: an exported value other than 0 would send RCCL into legacy IPC mode
+        sys.exit("HSA_ENABLE_IPC_MODE_LEGACY must be 0 for RCCL on this driver stack (dmabuf IPC); it is "
+                 f"{os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')!r}")
     dev_index = local_rank % max(1, torch.cuda.device_count())      # one rank per GPU (rehearsals may share one)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    if use_dist:
         # reporting only (barrier + MAX of elapsed time): the env path itself has no collective
+        if not launched:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -350,7 +388,7 @@ def main():
         bufs.reverse()
 
     def sync_all():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -367,96 +405,122 @@ def main():
     elapsed = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1)                                     # HIP events on the launch stream
     assert _lib.read_status(dev) == 0
+    # The roofline's launch duration: R more batches of `steps` launches each, back to back, every batch bracketed by HIP events on
+    # the launch stream (outside the timed region above, same buffers, same kernel): the MEDIAN batch is roofline.launch_us, so a
+    # 20-step driver run does not hang the headline fraction on one 1.4 ms sample.
+    n_batches = args.batches if args.batches > 0 else max(7, -(-140 // max(1, args.steps)))
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_batches + 1)]
+    evs[0].record()
+    for bi in range(n_batches):
+        for _ in range(args.steps):
+            step()
+        evs[bi + 1].record()
+    torch.cuda.synchronize()
+    batch_us = sorted(evs[i].elapsed_time(evs[i + 1]) / args.steps * 1e3 for i in range(n_batches))
+    launch_us, launch_min, launch_max = batch_us[len(batch_us) // 2], batch_us[0], batch_us[-1]
+    assert _lib.read_status(dev) == 0
     per_rank = None
-    if world > 1:
-        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+    if use_dist:
+        t = torch.tensor([elapsed, dev_ms, launch_us, launch_min, launch_max], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)                                     # reporting only: per-GPU figures beside the aggregate (config 4)
         shas = [None] * world
         dist.all_gather_object(shas, {"stream_id": stream_id, "sha": sample_sha, "device": torch.cuda.get_device_name(dev_index)})
         per_rank = [{"rank": r, "stream_id": shas[r]["stream_id"], "ms_per_step": float(x[0]) / args.steps * 1e3,
-                     "launch_us": float(x[1]) / args.steps * 1e3, "steps_per_s": n * args.steps / float(x[0]),
-                     "GBps": BYTES_PER_STEP * n / (float(x[1]) * 1e-3 / args.steps) / 1e9,
+                     "launch_us": float(x[2]), "launch_us_timed_region": float(x[1]) / args.steps * 1e3, "steps_per_s": n * args.steps / float(x[0]),
+                     "GBps": BYTES_PER_STEP * n / (float(x[2]) * 1e-6) / 1e9,
                      "initial_state_sha256_first_cubes": shas[r]["sha"], "sha_cubes": k}
                     for r, x in enumerate(every)]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, dev_ms = float(t[0]), float(t[1])
+        elapsed, dev_ms, launch_us, launch_max = float(t[0]), float(t[1]), float(t[2]), float(t[4])
+        launch_min = min(float(x[3]) for x in every)
+        # every rank is done with the process group here: nothing below (rank 0's extra configs, the CPU leg) keeps a peer waiting
+        # inside a collective
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
 
-    copy_gbps = None
-    if rank == 0:
-        # the measured device-copy ceiling SURVEY 8d asks for beside the vendor peak: the runtime's own D2D copy of the same buffers
-        for _ in range(3):
-            bufs[1].copy_(bufs[0])
-        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        c0.record()
-        for _ in range(20):
-            bufs[1].copy_(bufs[0])
-        c1.record()
-        torch.cuda.synchronize()
-        copy_gbps = 2 * bufs[0].numel() / (c0.elapsed_time(c1) / 20 * 1e-3) / 1e9
+    # the measured device-copy ceiling SURVEY 8d asks for beside the vendor peak: the runtime's own D2D copy of the same buffers
+    for _ in range(3):
+        bufs[1].copy_(bufs[0])
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c0.record()
+    for _ in range(20):
+        bufs[1].copy_(bufs[0])
+    c1.record()
+    torch.cuda.synchronize()
+    copy_gbps = 2 * bufs[0].numel() / (c0.elapsed_time(c1) / 20 * 1e-3) / 1e9
     kernel = _lib.describe(_lib.OP_STEP, CUBE, n, outputs=_lib.OUT_STATES | _lib.OUT_DONE)   # what the headline launches, from the library's own dispatch
     configs = None
-    if rank == 0 and not args.no_configs:
+    if not args.no_configs:
         del a, b, bufs
         torch.cuda.empty_cache()
         configs = other_configs(torch, ops, _lib, dev, acts)
         assert _lib.read_status(dev) == 0
 
-    if rank == 0:
-        steps_per_s = n * args.steps * world / elapsed
-        launch_s = dev_ms * 1e-3 / args.steps
-        achieved = BYTES_PER_STEP * n / launch_s / 1e9
-        traffic, traffic_source = None, None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-derived bytes per launch, if profiled
-        if os.path.exists(tfile) and n == N_CUBES:
-            try:
-                tj = json.load(open(tfile))
-                traffic = tj.get("k_step_bytes_per_launch")
-                traffic_source = (f"profiles/traffic.json: builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round {tj.get('round')} "
-                                  "over this same command (not re-measured in this run)")
-            except Exception:
-                traffic = None
-        state_mb = n * 54 / 1e6
-        pol = kernel.split("POL=")[1][0] if "POL=" in kernel else "?"
-        served = {"0": f"working set {2 * state_mb:.0f} MB fits the 256 MB Infinity Cache: rows default-cached, served on-die, NOT an HBM figure",
-                  "1": "input rows streamed (nt), output rows written through and kept (sc0 sc1): the next launch finds part of its input in the "
-                       "256 MB Infinity Cache, so DRAM traffic is below the fabric traffic the counters show; the nothing-cached figure is "
-                       "roofline.frac_hbm_only",
-                  "2": "input rows streamed (nt), output rows streamed (sc0 sc1 nt): every byte comes from and goes to HBM"}.get(pol, "")
-        workload = (f"3x3x3 apply_move + solved flag, {n} cubes per GPU per launch x {world} GPU(s), uint8 SoA [54][N] in 32768-cube tiles, "
-                    "ping-pong of two buffers; ")
-        workload += ("configs[1] shape at the metric's batch 4M" if n == N_CUBES else
-                     "BASELINE configs[3] shape: 1M cubes per GPU, rank-distinct RNG streams, no collective" if n == 1 << 20 else "custom batch")
-        out = {
-            "metric": "cube-move steps/sec, 3x3x3 batch 4M; HBM GB/s vs roofline at 1/2/4/8 GPU",
-            "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": workload, "cubes_per_gpu": n, "total_cubes": n * world, "bytes_per_step_algorithmic": BYTES_PER_STEP,
-                       "parallelism": f"{world} independent ranks, stream_id = rank, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": kernel, "launch_us": launch_s * 1e6,
-                         "algorithmic_bytes_per_launch": BYTES_PER_STEP * n,
-                         "served_by": "hbm" if pol == "2" else "hbm + infinity cache" if pol == "1" else "infinity cache",
-                         "frac_hbm_only": configs["hbm_only_frac"] if configs else None,
-                         "frac_hbm_only_note": "the same kernel at 2^24 cubes (1.8 GB ping-pong, nothing cached): configs.records, 'HBM-only point'",
-                         "device_copy_GBps": copy_gbps, "frac_of_device_copy": achieved / copy_gbps if copy_gbps else None,
-                         "device_copy_note": f"hipMemcpy D2D (torch copy_) of the same {state_mb:.0f} MB state buffer, read + write bytes",
-                         "note": served},
-        }
-        if per_rank:
-            out["per_gpu"] = per_rank
-            out["roofline"]["aggregate_GBps"] = sum(r["GBps"] for r in per_rank)
-            out["roofline"]["aggregate_frac_of_n_x_peak"] = out["roofline"]["aggregate_GBps"] / (HBM_PEAK_GBPS * world)
-        if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
-        if configs:
-            out["configs"] = configs
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    steps_per_s = n * args.steps * world / elapsed
+    launch_s = launch_us * 1e-6
+    achieved = BYTES_PER_STEP * n / launch_s / 1e9
+    traffic, traffic_source = None, None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-derived bytes per launch, if profiled
+    if os.path.exists(tfile) and n == N_CUBES:
+        try:
+            tj = json.load(open(tfile))
+            traffic = tj.get("k_step_bytes_per_launch")
+            traffic_source = (f"profiles/traffic.json: builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round {tj.get('round')} "
+                              "over this same command (not re-measured in this run)")
+        except Exception:
+            traffic = None
+    state_mb = n * 54 / 1e6
+    pol = kernel.split("POL=")[1][0] if "POL=" in kernel else "?"
+    served = {"0": f"working set {2 * state_mb:.0f} MB fits the 256 MB Infinity Cache: rows default-cached, served on-die, NOT an HBM figure",
+              "1": "input rows streamed (nt), output rows written through and kept (sc0 sc1): the next launch finds part of its input in the "
+                   "256 MB Infinity Cache, so DRAM traffic is below the fabric traffic the counters show; the nothing-cached figure is "
+                   "roofline.frac_hbm_only",
+              "2": "input rows streamed (nt), output rows streamed (sc0 sc1 nt): every byte comes from and goes to HBM"}.get(pol, "")
+    workload = (f"3x3x3 apply_move + solved flag, {n} cubes per GPU per launch x {world} GPU(s), uint8 SoA [54][N] in 32768-cube tiles, "
+                "ping-pong of two buffers; ")
+    workload += ("configs[1] shape at the metric's batch 4M" if n == N_CUBES else
+                 "BASELINE configs[3] shape: 1M cubes per GPU, rank-distinct RNG streams, no collective" if n == 1 << 20 else "custom batch")
+    out = {
+        "metric": "cube-move steps/sec, 3x3x3 batch 4M; HBM GB/s vs roofline at 1/2/4/8 GPU",
+        "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": workload, "cubes_per_gpu": n, "total_cubes": n * world, "bytes_per_step_algorithmic": BYTES_PER_STEP,
+                   "parallelism": f"{world} independent ranks, stream_id = rank, no collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                     "kernel": kernel, "launch_us": launch_us, "launch_us_min": launch_min, "launch_us_max": launch_max,
+                     "launch_us_timed_region": dev_ms / args.steps * 1e3,
+                     "launch_batches": n_batches, "launches_per_batch": args.steps,
+                     "launch_note": "launch_us = median over `launch_batches` back-to-back batches of `launches_per_batch` launches, each bracketed by "
+                                    "HIP events on the launch stream, run right after the timed region (N > 1: the slowest rank's median)",
+                     "algorithmic_bytes_per_launch": BYTES_PER_STEP * n,
+                     "achievable_GBps": HBM_ACHIEVABLE_GBPS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBPS,
+                     "achievable_note": "MI355X_MICROARCH.md: HBM 8 TB/s peak (spec), about 6.3 TB/s achievable",
+                     "served_by": "hbm" if pol == "2" else "hbm + infinity cache" if pol == "1" else "infinity cache",
+                     "frac_hbm_only": configs["hbm_only_frac"] if configs else None,
+                     "frac_hbm_only_note": "the same kernel at 2^24 cubes (1.8 GB ping-pong, nothing cached): per_config '16M step (HBM only)'",
+                     "device_copy_GBps": copy_gbps, "frac_of_device_copy": achieved / copy_gbps if copy_gbps else None,
+                     "device_copy_note": f"hipMemcpy D2D (torch copy_) of the same {state_mb:.0f} MB state buffer, read + write bytes",
+                     "note": served},
+    }
+    if configs:
+        out["roofline"]["per_config"] = per_config_summary(configs)
+        out["roofline"]["per_config_note"] = ("every other workload of BASELINE.json / SURVEY 8d, timed outside the headline region (median of 3 event-timed "
+                                              "batches): frac = bytes / (launch_us * 1e-6) / 8e12; full records under `configs`")
+    if per_rank:
+        out["per_gpu"] = per_rank
+        out["roofline"]["aggregate_GBps"] = sum(r["GBps"] for r in per_rank)
+        out["roofline"]["aggregate_frac_of_n_x_peak"] = out["roofline"]["aggregate_GBps"] / (HBM_PEAK_GBPS * world)
+        out["config"]["process_group"] = args.backend
+    if not args.no_cpu and world == 1:
+        out["cpu_baseline"] = cpu_baseline()
+    if configs:
+        out["configs"] = configs
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include <utility>
 
 #include "rc_tables.h"
@@ -587,53 +588,100 @@ __device__ __forceinline__ uint32_t onehot_bits4(const uint8_t *lds_code, int tp
 // (the generic loop below re-derives cube / row / column from the element index with two divisions per store).
 // NT = writer threads per pass, a multiple of 120 (so that it is a multiple of CPC for every format): 240 of a 256-thread
 // workgroup, 960 of the wide 960-thread form (15 waves sweeping ONE contiguous stream per compute unit).
+// The loop is software-pipelined: the code bytes of RC_DENSE_PIPE passes are read from LDS before the first of their stores is
+// issued, so a wave has that many 16-byte stores in flight per LDS round trip instead of one.
+// Build-time switches of the round-4 control experiment (tools/dense_control.py; the shipped build defines none of them):
+//   RC_DENSE_CTRL 1  the LDS read is replaced by a register value (what is left is address arithmetic + stores)
+//   RC_DENSE_CTRL 2  as 1, and the kernels skip the code loads, LDS writes and barriers too (store-only)
+//   RC_DENSE_AUX     cache policy of the dense stores (default: write-once stream, sc0 sc1 nt)
+#ifndef RC_DENSE_PIPE
+#define RC_DENSE_PIPE 4
+#endif
+#ifndef RC_DENSE_CTRL
+#define RC_DENSE_CTRL 0
+#endif
+#ifndef RC_DENSE_AUX
+#define RC_DENSE_AUX kAuxStreamStore
+#endif
+
+// the 16-byte chunk whose element d (of EPT) is the 1; all zero when d >= EPT
+template <class E>
+__device__ __forceinline__ Pk<4> onehot_chunk(uint32_t d) {
+    Pk<4> u;
+    if constexpr (sizeof(E) == 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u.d[j] = d == (uint32_t)j ? One<E>::v : 0u;
+    } else {
+        // the 1 sits in element d of 8: one 64-bit shift gives the half it falls into, two compares pick the half
+        const uint64_t x = (uint64_t)One<E>::v << ((d & 3u) << 4);
+        const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+        const bool lo_half = d < 4u, hi_half = d - 4u < 4u;
+        u.d[0] = lo_half ? xl : 0u; u.d[1] = lo_half ? xh : 0u;
+        u.d[2] = hi_half ? xl : 0u; u.d[3] = hi_half ? xh : 0u;
+    }
+    return u;
+}
+
 template <class T, class E, int NT = 240>
 __device__ __forceinline__ void dense_write_333(const uint8_t *lds_code, int tp, E *out, int ncubes, int tid) {
     static_assert(T::SIZE == 3 && T::R * T::C == 480 && T::C % 4 == 0 && NT % 120 == 0);
     constexpr int EPT = 16 / (int)sizeof(E), CPC = 480 / EPT, CPP = NT / CPC;   // elements per chunk, chunks per cube, cubes per pass
+    constexpr int U = RC_DENSE_PIPE;
+    constexpr uint32_t STEP = CPP * 480u * (uint32_t)sizeof(E);                 // bytes between a thread's consecutive passes
     if (tid >= NT) return;
     const int sub = tid / CPC, k = tid - sub * CPC;
     const __amdgpu_buffer_rsrc_t srd = make_srd(out);                           // `out` is workgroup-uniform
     uint32_t off = (uint32_t)sub * 480u * (uint32_t)sizeof(E) + (uint32_t)k * 16u;
-    if constexpr (sizeof(E) >= 2) {                                              // the whole chunk lies in one row (24 % EPT == 0)
-        const int e0 = k * EPT, r = e0 / T::C;
-        const uint32_t c0 = (uint32_t)(e0 - r * T::C);
-        const uint8_t *src = lds_code + r * tp;
-        for (int cube = sub; cube < ncubes; cube += CPP, off += CPP * 480u * (uint32_t)sizeof(E)) {
-            const uint32_t d = (uint32_t)src[cube] - c0;                         // which element of the chunk is the 1 (if < EPT)
-            Pk<4> u;
-            if constexpr (sizeof(E) == 4) {
+    // WHOLE: every pass of the pipelined group exists (ncubes is a multiple of U * CPP -- any full tile): no guards in the loop
+    auto sweep = [&](auto whole_c) {
+        constexpr bool WHOLE = decltype(whole_c)::value;
+        if constexpr (sizeof(E) >= 2) {                                          // the whole chunk lies in one row (24 % EPT == 0)
+            const int e0 = k * EPT, r = e0 / T::C;
+            const uint32_t c0 = (uint32_t)(e0 - r * T::C);
+            const uint8_t *src = lds_code + r * tp;
+            for (int cube = sub; cube < ncubes; cube += U * CPP, off += U * STEP) {
+                uint32_t d[U];                                                   // which element of the chunk is the 1 (if < EPT)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) u.d[j] = d == (uint32_t)j ? One<E>::v : 0u;
-            } else {
-#ifdef RC_DENSE_CMP    // round 2's form: eight compares + eight selects + four ORs per 16-byte chunk
-#pragma unroll
-                for (int j = 0; j < 4; ++j) u.d[j] = (d == (uint32_t)(2 * j) ? One<E>::v : 0u) | (d == (uint32_t)(2 * j + 1) ? One<E>::v << 16 : 0u);
-#else                  // the 1 sits in element d of 8: one 64-bit shift gives the half it falls into, two compares pick the half
-                const uint64_t x = (uint64_t)One<E>::v << ((d & 3u) << 4);
-                const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
-                const bool lo_half = d < 4u, hi_half = d - 4u < 4u;
-                u.d[0] = lo_half ? xl : 0u; u.d[1] = lo_half ? xh : 0u;
-                u.d[2] = hi_half ? xl : 0u; u.d[3] = hi_half ? xh : 0u;
+                for (int j = 0; j < U; ++j) {
+                    const int c = cube + j * CPP;
+#if RC_DENSE_CTRL
+                    d[j] = (uint32_t)(c & 7);
+#else
+                    d[j] = (WHOLE || c < ncubes ? (uint32_t)src[c] : 0xffu) - c0;
 #endif
-            }
-            bst<4, kAuxStreamStore>(srd, off, 0, u);
-        }
-    } else {                                                                     // u8: 16 elements may straddle two rows; per dword (4 elements, one row)
-        int rr[4];
-        uint32_t cc[4];
+                }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const int e = k * 16 + 4 * j; rr[j] = e / T::C; cc[j] = (uint32_t)(e - rr[j] * T::C); }
-        for (int cube = sub; cube < ncubes; cube += CPP, off += CPP * 480u) {
-            Pk<4> u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t d = (uint32_t)lds_code[rr[j] * tp + cube] - cc[j];
-                u.d[j] = d < 4u ? 1u << (8u * d) : 0u;
+                for (int j = 0; j < U; ++j)
+                    if (WHOLE || cube + j * CPP < ncubes) bst<4, RC_DENSE_AUX>(srd, off + (uint32_t)j * STEP, 0, onehot_chunk<E>(d[j]));
             }
-            bst<4, kAuxStreamStore>(srd, off, 0, u);
+        } else {                                                                 // u8: 16 elements may straddle two rows; per dword (4 elements, one row)
+            int rr[4];
+            uint32_t cc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int e = k * 16 + 4 * j; rr[j] = e / T::C; cc[j] = (uint32_t)(e - rr[j] * T::C); }
+            for (int cube = sub; cube < ncubes; cube += U * CPP, off += U * STEP) {
+                Pk<4> u[U];
+#pragma unroll
+                for (int q = 0; q < U; ++q) {
+                    const int c = cube + q * CPP;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+#if RC_DENSE_CTRL
+                        const uint32_t d = (uint32_t)((c + j) & 7);
+#else
+                        const uint32_t d = (WHOLE || c < ncubes ? (uint32_t)lds_code[rr[j] * tp + c] : 0xffu) - cc[j];
+#endif
+                        u[q].d[j] = d < 4u ? 1u << (8u * d) : 0u;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < U; ++q)
+                    if (WHOLE || cube + q * CPP < ncubes) bst<4, RC_DENSE_AUX>(srd, off + (uint32_t)q * STEP, 0, u[q]);
+            }
         }
-    }
+    };
+    if (ncubes % (U * CPP) == 0) sweep(std::true_type{});                        // workgroup-uniform
+    else sweep(std::false_type{});
 }
 
 template <class T, class E>

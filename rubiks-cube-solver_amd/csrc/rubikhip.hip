@@ -240,12 +240,16 @@ __global__ void __launch_bounds__(kDenseBlock) k_step_dense(StepArgs a, E *dense
     const uint32_t lo = threadIdx.x * 4;
     // grid-stride over tiles: large batches run a capped grid (launch_dense_t), every workgroup a few tiles in turn
     for (int64_t tile0 = (int64_t)blockIdx.x * TILE; tile0 < a.n; tile0 += (int64_t)gridDim.x * TILE) {
+#if RC_DENSE_CTRL < 2                                                  // (control experiment builds only: rc_device.h RC_DENSE_CTRL)
         if (lo < TILE && tile0 + lo < a.n) dense_produce<T, MOVE, STORE>(a, tile0, lo, lds_code, TP);
         __syncthreads();
+#endif
         const int64_t left = a.n - tile0;
         const int ncubes = left < TILE ? (int)left : TILE;
         dense_write<T, E>(lds_code, TP, dense + tile0 * (T::R * T::C), ncubes, threadIdx.x, kDenseBlock);
+#if RC_DENSE_CTRL < 2
         __syncthreads();                                               // the code tile is reused by the next iteration
+#endif
     }
 }
 
@@ -255,17 +259,21 @@ __global__ void __launch_bounds__(kDenseBlock) k_code_to_dense(const uint8_t *co
     __shared__ __attribute__((aligned(16))) uint8_t lds_code[T::SLOTS * TP];
     const uint32_t lo = threadIdx.x * 4;
     for (int64_t tile0 = (int64_t)blockIdx.x * TILE; tile0 < n; tile0 += (int64_t)gridDim.x * TILE) {
-    if (lo < TILE && tile0 + lo < n) {
-        const __amdgpu_buffer_rsrc_t r = make_srd(code + tile_off(tile0, code_pitch, shift, T::SLOTS));
-        const uint32_t rs = (uint32_t)code_pitch;
+#if RC_DENSE_CTRL < 2
+        if (lo < TILE && tile0 + lo < n) {
+            const __amdgpu_buffer_rsrc_t r = make_srd(code + tile_off(tile0, code_pitch, shift, T::SLOTS));
+            const uint32_t rs = (uint32_t)code_pitch;
 #pragma unroll
-        for (int p = 0; p < T::SLOTS; ++p) *reinterpret_cast<uint32_t *>(lds_code + p * TP + lo) = bld<1, kAuxCached>(r, lo, p * rs).d[0];
-    }
-    __syncthreads();
-    const int64_t left = n - tile0;
-    const int ncubes = left < TILE ? (int)left : TILE;
-    dense_write<T, E>(lds_code, TP, dense + tile0 * (T::R * T::C), ncubes, threadIdx.x, kDenseBlock);
-    __syncthreads();
+            for (int p = 0; p < T::SLOTS; ++p) *reinterpret_cast<uint32_t *>(lds_code + p * TP + lo) = bld<1, kAuxCached>(r, lo, p * rs).d[0];
+        }
+        __syncthreads();
+#endif
+        const int64_t left = n - tile0;
+        const int ncubes = left < TILE ? (int)left : TILE;
+        dense_write<T, E>(lds_code, TP, dense + tile0 * (T::R * T::C), ncubes, threadIdx.x, kDenseBlock);
+#if RC_DENSE_CTRL < 2
+        __syncthreads();
+#endif
     }
 }
 
@@ -295,6 +303,7 @@ __global__ void __launch_bounds__(kWideBlock) k_code_to_dense_wide(const uint8_t
     int buf = 0;
     for (int64_t k = 0; k < mine; ++k, buf ^= 1) {
         const int64_t tile0 = first + ((start + k) % mine) * TILE;
+#if RC_DENSE_CTRL < 2
         if (lo < TILE && tile0 + lo < n) {
             const __amdgpu_buffer_rsrc_t r = make_srd(code + tile_off(tile0, code_pitch, shift, T::SLOTS));
             const uint32_t rs = (uint32_t)code_pitch;
@@ -302,6 +311,7 @@ __global__ void __launch_bounds__(kWideBlock) k_code_to_dense_wide(const uint8_t
             for (int p = 0; p < T::SLOTS; ++p) *reinterpret_cast<uint32_t *>(lds_code[buf] + p * TP + lo) = bld<1, kAuxCached>(r, lo, p * rs).d[0];
         }
         __syncthreads();                                            // double-buffered tile: one barrier per tile is enough
+#endif
         const int64_t left = n - tile0;
         const int ncubes = left < TILE ? (int)left : TILE;
         dense_write_333<T, E, kWideBlock>(lds_code[buf], TP, dense + tile0 * (T::R * T::C), ncubes, threadIdx.x);

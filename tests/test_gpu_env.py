@@ -1,11 +1,13 @@
 """Env surface on the GPU: VecCubeEnv and the CubeEnv facade against the oracle env and the
 reference's golden vectors (reset KATs, ADI samples with the stub model).  GPU only."""
 import copy
+import os
 
 import numpy as np
 import pytest
 import torch
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
@@ -616,6 +618,34 @@ def test_envs_in_several_processes_share_one_gpu(oracle, golden):
         i, j = list(gr["seeds"]).index(rank * 10), list(gr["ks"]).index(7)
         assert (got[rank][1] == gr["stickers"][i, j]).all(), rank
     assert not (finals[0] == finals[1]).all() and not (finals[1] == finals[2]).all()
+
+
+def test_forked_workers_build_their_own_envs(oracle, golden, tmp_path):
+    """The reference starts its workers with mp.Process -- fork on Linux -- and each builds its env inside the child
+    (train.py:89-91,141; SURVEY 8b "usable after fork in 14 workers").  tests/fork_workers.py does exactly that with this package:
+    the parent imports it, never touches the GPU, forks 3 workers; every worker's reset(seed = rank*10, 7) is the reference's
+    (G4, reset_333.npz) and its 50 steps equal the oracle's replay (stickers, one-hot columns, reward, done)."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fork_workers.py"), str(tmp_path), "3"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+    gr = golden("reset_333")
+    pids = set()
+    for rank in range(3):
+        w = np.load(tmp_path / f"w{rank}.npz")
+        i, j = list(gr["seeds"]).index(rank * 10), list(gr["ks"]).index(7)
+        assert (w["after_reset"] == gr["stickers"][i, j]).all(), rank
+        assert (w["first"].argmax(-1) == gr["cols"][i, j]).all() and w["first"].sum() == 20, rank
+        st = gr["stickers"][i, j].astype(np.uint8)[None]
+        for t, a in enumerate(w["actions"]):
+            st, code, done, rew = oracle.step(3, st, np.array([a], dtype=np.uint8))
+            assert (w["stickers"][t] == st[0]).all(), (rank, t)
+            assert (w["onehots"][t].argmax(-1) == code[0]).all() and w["onehots"][t].sum() == 20 and w["onehots"][t].dtype == np.int64
+            assert w["rewards"][t] == rew[0] and bool(w["dones"][t]) == bool(done[0])
+        pids.add(int(w["pid"]))
+        assert int(w["ppid"]) not in pids
+    assert len(pids) == 3                                      # three different worker processes, one forking parent
 
 
 def test_checkpoint_traces_replay_on_the_hip_222_path(mod, golden):

@@ -331,7 +331,7 @@ import numpy as np
 from rubiks_cube_solver_amd import dist as d
 from oracle.oracle_np import Oracle
 rank, ws, local = d.init(backend="gloo")
-assert ws == 2
+assert ws == int(os.environ["RC_WS"])
 lo, hi = d.shard(1001, rank, ws)
 orc = Oracle()
 out = orc.adi(3, hi - lo, 6, seed=77, stream=d.rng_stream(rank), walk0=0, want_children=False)   # rank-local walks, own stream
@@ -352,22 +352,42 @@ def _free_port():
         return str(sock.getsockname()[1])
 
 
+def _run_gloo_ranks(tmp_path, ws):
+    import json
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, RC_ROOT=ROOT, RC_OUT=str(tmp_path), RC_WS=str(ws), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ws}", "--master-addr", "127.0.0.1",
+           "--master-port", _free_port(), str(script)]
+    subprocess.run(cmd, check=True, env=env, timeout=480, capture_output=True)
+    return [json.load(open(tmp_path / f"r{i}.json")) for i in range(ws)]
+
+
 def test_two_rank_gloo_sharding(tmp_path):
     """world_size 2 on CPU (gloo): disjoint shards, rank-distinct RNG streams, reporting reductions only.
     This exercises the HOST side of the N>1 path only -- dist.py's shard / rng_stream / reductions, with the oracle
     standing in for the per-rank generator; no kernel of librubikhip.so runs here.  The kernels' side of the same
     contract (stream_id = rank on a shared GPU, one process each) is tests/test_gpu_env.py::
     test_envs_in_several_processes_share_one_gpu and tests/test_bench_contract.py::test_bench_two_ranks_rehearsal."""
-    import json
-    script = tmp_path / "worker.py"
-    script.write_text(_GLOO_WORKER)
-    env = dict(os.environ, RC_ROOT=ROOT, RC_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", _free_port(), str(script)]
-    subprocess.run(cmd, check=True, env=env, timeout=240, capture_output=True)
-    r0, r1 = (json.load(open(tmp_path / f"r{i}.json")) for i in (0, 1))
+    r0, r1 = _run_gloo_ranks(tmp_path, 2)
     assert (r0["lo"], r0["hi"], r1["lo"], r1["hi"]) == (0, 501, 501, 1001)
     assert r0["total"] == r1["total"] == 1001.0 and r0["max"] == r1["max"] == 1.0
     assert r0["first_actions"] != r1["first_actions"]           # independent streams per rank
     from oracle.oracle_np import Oracle
     assert r0["first_actions"] == Oracle().rng_actions(77, 0, 0, 6, 12).tolist()  # reproducible
+
+
+def test_eight_rank_streams_and_shards(tmp_path):
+    """BASELINE config 4's world size (8 ranks) on CPU over gloo: eight contiguous shards that tile the batch, eight RNG streams
+    that are each the oracle's (seed, stream_id = rank) stream and pairwise different, SUM / MAX reductions over all eight.
+    (A GPU box of this pool admits at most 6 GPU processes per job, so the 8-rank shape is rehearsed here and the kernels' side
+    with 5 ranks in tests/test_bench_contract.py::test_bench_many_ranks_rehearsal.)"""
+    from oracle.oracle_np import Oracle
+    from rubiks_cube_solver_amd import dist as d
+    rs = _run_gloo_ranks(tmp_path, 8)
+    assert [(r["lo"], r["hi"]) for r in rs] == [d.shard(1001, k, 8) for k in range(8)] and rs[0]["lo"] == 0 and rs[-1]["hi"] == 1001
+    assert all(r["total"] == 1001.0 and r["max"] == 4.0 for r in rs)
+    orc = Oracle()
+    for k, r in enumerate(rs):
+        assert r["first_actions"] == orc.rng_actions(77, d.rng_stream(k), 0, 6, 12).tolist(), k
+    assert len({tuple(r["first_actions"]) for r in rs}) == 8

@@ -10,8 +10,11 @@ shims:
 Nothing from the reference is copied: the fixtures hold inputs (action sequences,
 seeds, stub-model weights) and the outputs the reference computed for them.
 
-    python -B tests/golden/make_golden.py            # everything
-    python -B tests/golden/make_golden.py mcts       # only the named groups (tables walks reset adi expand encode mcts rollout adi_deepcube replay mcts_guided)
+    python -B tests/golden/make_golden.py                 # everything, into tests/golden/
+    python -B tests/golden/make_golden.py mcts            # only the named groups (tables walks reset adi expand encode mcts rollout adi_deepcube replay mcts_guided)
+    python -B tests/golden/make_golden.py --out DIR       # write somewhere else
+    python -B tests/golden/make_golden.py --check         # regenerate into a temp dir, compare every array with the committed fixtures
+                                                          # (11 x IDENTICAL; exit status 1 otherwise) -- tests/test_oracle.py runs it
 
 Fixtures written (all small, np.savez_compressed):
   tables_333.npz   G1  tables as data (perm table, piece defs, hash weights, LUTs)
@@ -44,6 +47,18 @@ import numpy as np
 
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = HERE          # --out DIR / --check write somewhere else; the committed fixtures live in HERE
+FIXTURES = ("tables", "walks", "reset", "adi", "expand", "encode", "mcts", "mcts_guided", "rollout", "adi_deepcube", "replay")
+
+
+def out_path(name):
+    return os.path.join(OUT, name)
+
+
+def earlier_fixture(name):
+    """A fixture an earlier group wrote in this run (OUT), else the committed one."""
+    p = os.path.join(OUT, name)
+    return p if os.path.exists(p) else os.path.join(HERE, name)
 
 
 def import_reference():
@@ -76,8 +91,9 @@ def cols_of(onehot):
     return np.argmax(oh, 1).astype(np.uint8)
 
 
-def main():
-    groups = set(sys.argv[1:])
+def generate(groups):
+    """Run the reference and write the named fixture groups (all when empty) into OUT.  The groups that only need the env and a
+    model (mcts, rollout, adi_deepcube, replay, mcts_guided) run LAST: `replay` reads the stub-model weights of G5's adi_333.npz."""
     want = lambda g: not groups or g in groups
     torch, cube_env, py333 = import_reference()
     torch.set_num_threads(1)
@@ -89,6 +105,9 @@ def main():
     env = cube_env.CubeEnv(dev, cube_size=3)
     assert env.action_to_sim_action[3] == names
     assert [py333.moveInds[n] for n in names] == list(range(12))
+    late = {"mcts", "rollout", "adi_deepcube", "replay", "mcts_guided"}
+    if not groups or groups - late:
+        base_fixtures(torch, cube_env, py333, env, dev, A, names)
     if want("mcts"):
         golden_mcts(torch, cube_env, env)
     if want("rollout"):
@@ -99,10 +118,16 @@ def main():
         golden_replay(torch, env)
     if want("mcts_guided"):
         golden_mcts_guided(torch, cube_env, env)
-    if groups and not (groups - {"mcts", "rollout", "adi_deepcube", "replay", "mcts_guided"}):
-        return
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")
+
+
+def base_fixtures(torch, cube_env, py333, env, dev, A, names):
+    """G1-G7 (tables, walks, reset, adi, expand, encode): always regenerated together, in this order (the legacy-RNG state of one
+    block is not used by the next: every block seeds what it draws)."""
     np.savez_compressed(
-        os.path.join(HERE, "tables_333.npz"),
+        out_path("tables_333.npz"),
         moveDefs=py333.moveDefs.astype(np.uint8),
         corner_pieceDefs=py333.corner_pieceDefs.astype(np.uint8),
         edge_pieceDefs=py333.edge_pieceDefs.astype(np.uint8),
@@ -149,7 +174,7 @@ def main():
     # onehot dtype / values as the reference emits them
     st, _, _, _ = env.step(0)
     np.savez_compressed(
-        os.path.join(HERE, "walks_333.npz"),
+        out_path("walks_333.npz"),
         single_stickers=single, single_cols=single_cols, single_done=single_done,
         actions=actions, stickers=stickers, cols=cols, done=done, reward=reward,
         sha256=np.array(h.hexdigest()), onehot_dtype=np.array(str(st.dtype)),
@@ -174,7 +199,7 @@ def main():
     np.random.seed(777)
     assert (np.random.get_state()[1] == before).all()
     np.savez_compressed(
-        os.path.join(HERE, "reset_333.npz"),
+        out_path("reset_333.npz"),
         seeds=seeds, ks=ks, actions=r_actions, stickers=r_stickers, cols=r_cols,
     )
 
@@ -218,7 +243,7 @@ def main():
     assert (adi_tv[:, 0] == 1.0).all()  # depth 1: the inverse move solves the cube
     # dedicated get_target_value cases: 2 moves that cancel etc.
     np.savez_compressed(
-        os.path.join(HERE, "adi_333.npz"),
+        out_path("adi_333.npz"),
         w=w_lin, b=b_lin, temperature=np.float64(temperature), seed=np.int64(2024),
         actions=adi_actions, cols=adi_cols, target_value=adi_tv, target_policy=adi_tp,
         scramble_count=adi_sc, error=adi_err,
@@ -244,7 +269,7 @@ def main():
             ch_cols[i, a] = cols_of(st)
             ch_done[i, a] = dn
     np.savez_compressed(
-        os.path.join(HERE, "expand_333.npz"),
+        out_path("expand_333.npz"),
         leaf_actions=leaf_actions, leaves=leaves, child_stickers=ch_st,
         child_cols=ch_cols, child_done=ch_done,
     )
@@ -266,13 +291,10 @@ def main():
     rec = np.concatenate([rec, np.repeat(rng.integers(0, 6, (32, 6)), 9, axis=1)])
     rec_solved = np.array([py333.isSolved_3(s) for s in rec], np.uint8)
     np.savez_compressed(
-        os.path.join(HERE, "encode_333.npz"),
+        out_path("encode_333.npz"),
         stickers=arb.astype(np.uint8), cols=arb_cols, solved=arb_solved,
         recoloured=rec.astype(np.uint8), recoloured_solved=rec_solved,
     )
-    for f in sorted(os.listdir(HERE)):
-        if f.endswith(".npz"):
-            print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 
 def golden_rollout(torch, env):
@@ -303,7 +325,7 @@ def golden_rollout(torch, env):
         out["actions_mask" if mask else "actions"] = acts
         out["solved_at_mask" if mask else "solved_at"] = solved_at
     sd = {"sd_" + k: v.numpy() for k, v in net.state_dict().items()}
-    np.savez_compressed(os.path.join(HERE, "rollout_333.npz"), ks=np.array(ks), n_seeds=np.int64(n_seeds), T=np.int64(T), **out, **sd)
+    np.savez_compressed(out_path("rollout_333.npz"), ks=np.array(ks), n_seeds=np.int64(n_seeds), T=np.int64(T), **out, **sd)
     print("rollout: solved", int((out["solved_at"] > 0).sum()), "masked", int((out["solved_at_mask"] > 0).sum()))
 
 
@@ -320,7 +342,7 @@ def golden_adi_deepcube(torch, env):
     shape = (n_cubes, depth)
     sd = {"sd_" + k: v.numpy() for k, v in net.state_dict().items()}
     np.savez_compressed(
-        os.path.join(HERE, "adi_deepcube_333.npz"), seed=np.int64(seed), temperature=np.float64(temperature),
+        out_path("adi_deepcube_333.npz"), seed=np.int64(seed), temperature=np.float64(temperature),
         cols=np.stack([cols_of(b["state"]) for b in buf]).reshape(*shape, 20),
         target_value=np.array([b["target_value"] for b in buf], np.float64).reshape(shape),
         target_policy=np.array([b["target_policy"] for b in buf], np.int64).reshape(shape),
@@ -335,7 +357,7 @@ def golden_replay(torch, env):
     import utils as ref_utils
     from torch.utils.data import DataLoader
 
-    g5 = np.load(os.path.join(HERE, "adi_333.npz"))
+    g5 = np.load(earlier_fixture("adi_333.npz"))
     w_lin, b_lin = torch.tensor(g5["w"]), torch.tensor(g5["b"])
 
     class StubModel(torch.nn.Module):
@@ -388,7 +410,7 @@ def golden_replay(torch, env):
     env.get_random_samples(small, StubModel(), 5, 8, temperature)
     small.get_prioritized_sample()
     out["small_idx"] = np.asarray(small.prioritized_idx, np.int64)
-    np.savez_compressed(os.path.join(HERE, "replay_333.npz"), buf_size=np.int64(buf_size), sample_size=np.int64(sample_size),
+    np.savez_compressed(out_path("replay_333.npz"), buf_size=np.int64(buf_size), sample_size=np.int64(sample_size),
                         mem_cols=mem_cols, mem_err=mem_err, upd_idx=upd_idx, upd_err=upd_err, **out)
     print("replay:", len(out["idx1"]), "prioritised of", buf_size, "dtypes", list(out["item_dtypes"]))
 
@@ -464,7 +486,7 @@ def golden_mcts_guided(torch, cube_env, env):
                 n_nodes += 1
         sol.append(a); p_vis.append(vis); p_val.append(val); p_vl.append(vl); p_len.append(n_nodes)
     np.savez_compressed(
-        os.path.join(HERE, "mcts_guided_333.npz"),
+        out_path("mcts_guided_333.npz"),
         table_cols=t_cols, table_depth=t_depth, table_back=t_back,
         seeds=np.array([c[0] for c in cases]), ks=np.array([c[1] for c in cases]),
         random_seed=np.array([5000 + 13 * s + k for s, k in cases]), sims=np.array(sims), solution=np.stack(sol),
@@ -519,13 +541,65 @@ def golden_mcts(torch, cube_env, env):
         env.reset(seed=int(s), scramble_count=1000)
         long_st[i] = env.sim_cube
     np.savez_compressed(
-        os.path.join(HERE, "mcts_333.npz"),
+        out_path("mcts_333.npz"),
         wv=wv, wp=wp, seeds=np.array([c[0] for c in cases]), ks=np.array([c[1] for c in cases]),
         random_seed=np.array([1000 + 17 * s + k for s, k in cases]), sims=np.array(sims), solution=np.stack(sol),
         root_visits=np.stack(root_visits), root_values=np.stack(root_values),
         long_seeds=seeds_long, long_k=np.int64(1000), long_stickers=long_st,
     )
     print("mcts:", list(zip(cases, sims)))
+
+
+def compare(dir_a, dir_b, names):
+    """Array-by-array comparison (keys, dtype, shape, values) of the named fixtures in two directories."""
+    bad = 0
+    for name in names:
+        fa, fb = os.path.join(dir_a, name), os.path.join(dir_b, name)
+        if not (os.path.exists(fa) and os.path.exists(fb)):
+            print(f"{name}: MISSING ({'regenerated' if not os.path.exists(fa) else 'committed'} file absent)")
+            bad += 1
+            continue
+        a, b = np.load(fa), np.load(fb)
+        diffs = [k for k in sorted(set(a.files) | set(b.files))
+                 if k not in a.files or k not in b.files or a[k].dtype != b[k].dtype or a[k].shape != b[k].shape
+                 or not np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f")]
+        print(f"{name}: {'IDENTICAL' if not diffs else 'DIFFERENT in ' + ', '.join(diffs)} ({len(a.files)} arrays)")
+        bad += bool(diffs)
+    return bad
+
+
+def main():
+    import argparse
+    import tempfile
+    global OUT
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("groups", nargs="*", help=f"fixture groups to (re)generate, default all: {' '.join(FIXTURES)}")
+    ap.add_argument("--out", default=None, help="directory to write into (default: tests/golden itself)")
+    ap.add_argument("--check", action="store_true",
+                    help="regenerate into a temporary directory and compare every array (dtype, shape, values) with the committed fixtures; "
+                         "exit status 1 on any difference")
+    args = ap.parse_args()
+    unknown = set(args.groups) - set(FIXTURES)
+    if unknown:
+        sys.exit(f"unknown groups: {sorted(unknown)}")
+    if not os.path.isdir(REF):
+        sys.exit(f"{REF} is not here: the fixtures can only be regenerated in the build container")
+    if args.check:
+        with tempfile.TemporaryDirectory(prefix="golden_check_") as tmp:
+            OUT = tmp
+            generate(set(args.groups))
+            base = {"tables", "walks", "reset", "adi", "expand", "encode"}
+            which = set(args.groups) or set(FIXTURES)
+            if which & base:
+                which |= base                                      # G1-G7 are regenerated together
+            names = [f"{g}_333.npz" for g in FIXTURES if g in which]
+            bad = compare(tmp, HERE, names)
+        print(f"{len(names) - bad} of {len(names)} fixtures IDENTICAL to the committed ones")
+        sys.exit(1 if bad else 0)
+    if args.out:
+        os.makedirs(args.out, exist_ok=True)
+        OUT = args.out
+    generate(set(args.groups))
 
 
 if __name__ == "__main__":

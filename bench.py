@@ -225,8 +225,10 @@ def other_configs(torch, ops, _lib, dev, acts):
     for dt, fmt, name, bpc in ((torch.float32, _lib.FMT_F32, "f32", 1920), (torch.bfloat16, _lib.FMT_BF16, "bf16", 960)):
         oh = torch.empty((m, 20, 24), dtype=dt, device=dev)
         t = timed(lambda: ops.apply_moves(a1, b1, acts, m, CUBE, rew, done, oh, fmt), 10, 2)
-        rec(f"1M step+dense {name}", f"3x3x3 batch 1M, apply_move + reward + done + fused dense {name} one-hot [N,20,24]", D(_lib.OP_STEP, CUBE, m, outputs=ST | REW, fmt=fmt), m, "steps",
-            114 + bpc, t)
+        rec(f"1M step+dense {name}", f"3x3x3 batch 1M, apply_move + reward + done + fused dense {name} one-hot [N,20,24]",
+            D(_lib.OP_STEP, CUBE, m, outputs=ST | REW | _lib.OUT_WORKSPACE, fmt=fmt), m, "steps", 114 + bpc, t,
+            "ops.apply_moves = rc_apply_moves_ws: one call; float32 runs as two launches (step + compact code into a caller-owned workspace, then "
+            "the front writer), the 16-bit formats as one launch")
         del oh
     # compact code -> dense one-hot: what adi_samples, the replay sink and the lockstep search launch (the wide writer)
     code1 = ops.alloc_code(m, CUBE, dev)

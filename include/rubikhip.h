@@ -8,7 +8,8 @@
  *
  * Conventions
  *   - All buffers are DEVICE memory owned by the caller (e.g. PyTorch-ROCm tensors); the
- *     library allocates nothing but its constant tables and one status word per device.
+ *     library allocates nothing but its constant tables and one status word per device (rc_apply_moves_ws takes a
+ *     caller-owned workspace).
  *   - State layout.  Cube states are structure-of-arrays uint8, values 0..5, S = 54
  *     (cube_size 3) or 24 (cube_size 2) rows, in TILES of `pitch` cubes:
  *         sticker s of cube n lives at st[(n / pitch) * S * pitch + s * pitch + n % pitch].
@@ -100,6 +101,16 @@ int rc_fill_solved(uint8_t *st, int64_t n_cubes, int64_t pitch, int cube_size, v
 int rc_apply_moves(const uint8_t *in, uint8_t *out, const uint8_t *actions, int64_t n_cubes,
                    int64_t pitch_in, int64_t pitch_out, int cube_size, float *reward,
                    uint8_t *done, void *onehot, int fmt, int64_t code_pitch, void *stream);
+/* rc_apply_moves with a caller-owned WORKSPACE (device memory, 16-byte aligned, rc_workspace_bytes(RC_OP_STEP, ...) bytes; its
+ * contents are scratch).  Results are identical to rc_apply_moves.  With a dense `fmt` on large 3x3x3 batches the workspace lets the
+ * call run as two launches -- step + reward + done + compact code into the workspace, then the front writer
+ * (k_code_to_dense_front) -- so that the dense stream leaves the chip as one sweeping window: 0.80-0.94 of the HBM peak on every
+ * allocation instead of 0.67-0.87 depending on where the buffer lives (DESIGN.md "Dense one-hot").  A NULL or too small workspace,
+ * or a call that has no use for one (rc_workspace_bytes() == 0), runs exactly rc_apply_moves.  The library still allocates nothing. */
+int64_t rc_workspace_bytes(int op, int cube_size, int64_t n_cubes, int fmt);
+int rc_apply_moves_ws(const uint8_t *in, uint8_t *out, const uint8_t *actions, int64_t n_cubes,
+                      int64_t pitch_in, int64_t pitch_out, int cube_size, float *reward, uint8_t *done,
+                      void *onehot, int fmt, int64_t code_pitch, void *workspace, int64_t workspace_bytes, void *stream);
 /* Same with a per-call tuning override (see "Tuning override" at the end; 0 = rc_apply_moves). */
 int rc_apply_moves_ex(const uint8_t *in, uint8_t *out, const uint8_t *actions, int64_t n_cubes,
                       int64_t pitch_in, int64_t pitch_out, int cube_size, float *reward,
@@ -239,6 +250,7 @@ int rc_read_status(uint32_t *status, void *stream);
 #define RC_OUT_REWARD 8u
 #define RC_OUT_INPLACE 16u
 #define RC_OUT_DONE 32u
+#define RC_OUT_WORKSPACE 64u   /* RC_OP_STEP with a dense fmt: what rc_apply_moves_ws launches when given its workspace */
 int rc_describe_dispatch(int op, int cube_size, int64_t n, int depth, unsigned outputs, int fmt, int variant,
                          char *buf, int buflen);
 
@@ -253,8 +265,10 @@ const char *rc_last_error(void);
  *   hundreds   streaming expansion (stickers + flags by few persistent waves): 1..7 -> 128, 192, 256, 384, 512, 768, 1024 waves, 8 -> off
  *   thousands  (2 digits) parts per walk group for expansion / ADI (1..A, rounded up to a divisor of A)
  *   100000s    dense one-hot writer: 1 -> 64-cube tiles, 2 -> 256-cube tiles (256-thread workgroups), 3 -> the wide form of
- *              rc_onehot_from_code (960-thread workgroups sweeping contiguous tile ranges; 3x3x3, the default from 2^17 cubes;
- *              the thousands field then gives the wanted workgroup count / 16, the tens digit the sweep skew)
+ *              rc_onehot_from_code (960-thread workgroups sweeping contiguous tile ranges; 3x3x3; the thousands field then gives
+ *              the wanted workgroup count / 16, the tens digit the sweep skew), 4 -> the front form of rc_onehot_from_code
+ *              (one 3840-byte pass per workgroup; 3x3x3, the default from 2^17 cubes; tens digit 2 -> one linear front instead
+ *              of one front per XCD).  Any non-zero value makes rc_apply_moves_ws ignore its workspace.
  *   millions   (2 digits) depth segments per walk group of the ADI kernel (1..16, clamped to depth) */
 
 #ifdef __cplusplus

@@ -107,6 +107,10 @@ template <> struct RowPolicy<0> { static constexpr int LD = kAuxCached, ST = kAu
 template <> struct RowPolicy<1> { static constexpr int LD = kAuxStreamLoad, ST = kAuxKeepStore, SIDE = RC_SIDE_AUX_POL1; };
 template <> struct RowPolicy<2> { static constexpr int LD = kAuxStreamLoad, ST = kAuxStreamStore, SIDE = kAuxStreamStore; };
 template <> struct RowPolicy<3> { static constexpr int LD = kAuxCached, ST = kAuxCached, SIDE = kAuxStreamStore; };
+// POL 4 (rc_apply_moves_ws beyond the Infinity Cache): state rows streamed both ways, the side outputs -- the compact code the front
+// writer reads back in the very next launch -- written through and KEPT.  Streamed past the cache instead, the code comes back from
+// HBM with a miss latency per front workgroup: the two-launch route drops from 0.89 to 0.52 of peak at 2^21 cubes.
+template <> struct RowPolicy<4> { static constexpr int LD = kAuxStreamLoad, ST = kAuxStreamStore, SIDE = kAuxKeepStore; };
 
 // One lane = 4*V consecutive cubes.  MOVE: apply actions; STORE: write the state rows;
 // CODE: write the compact code rows.  FULL: every pack of the wave lies
@@ -315,6 +319,64 @@ __global__ void __launch_bounds__(kWideBlock) k_code_to_dense_wide(const uint8_t
         const int64_t left = n - tile0;
         const int ncubes = left < TILE ? (int)left : TILE;
         dense_write_333<T, E, kWideBlock>(lds_code[buf], TP, dense + tile0 * (T::R * T::C), ncubes, threadIdx.x);
+    }
+}
+
+// FRONT form of the code -> dense writer (3x3x3, large batches; round 4, profiles/r04_dense_control.json): 3840-byte passes, each
+// written by ONE store instruction per lane of a workgroup that then ends -- 240 threads write the 2 / 4 / 8 whole cubes (f32 /
+// 16-bit / u8) of a pass.  Workgroups start in address order and live for one store round trip, so at any moment the chip writes a
+// dense window of a few MB that sweeps the buffer front to back, the way a fill kernel does: a store-only kernel of this shape runs
+// at 0.88-0.93 of the 8 TB/s peak on EVERY allocation, while any shape whose workgroups write a longer private stream (8 KiB
+// chunks and up, persistent or not) lands at 0.65-0.85 depending on where the buffer lives (tools/dense_shape.hip).
+// Only 2048 workgroups are resident and each holds 3840 bytes per front, so throughput = resident bytes / workgroup lifetime:
+//   * fronts: blocks b, b + 8, ... (one XCD: blocks are dealt round-robin over the 8 XCDs) take CONSECUTIVE passes of one eighth
+//     of the buffer, so the code lines a pass needs were fetched into this XCD's L2 by the passes just before it (8 fronts);
+//   * F: every workgroup serves F such fronts per XCD (one pass each, all code bytes loaded before the first store), which
+//     multiplies the bytes in flight per workgroup lifetime without lengthening any front's private stream.
+// No LDS, no barrier: every thread fetches the one code byte (u8: two) its chunk depends on straight from the code rows.
+// (Wave-uniform scalar loads of the rows + a select chain were tried and lost: 0.64 against 0.81, bf16.)
+template <class T, class E, int F>
+__global__ void __launch_bounds__(256) k_code_to_dense_front(const uint8_t *__restrict__ code, int64_t n, int64_t code_pitch, int shift, E *__restrict__ dense,
+                                                             int64_t per_xcd, int64_t per_front) {
+    static_assert(T::SIZE == 3);
+    constexpr int EPT = 16 / (int)sizeof(E), CPC = 480 / EPT, CPP = 240 / CPC;   // elements per chunk, chunks per cube, cubes per pass
+    const int tid = threadIdx.x;
+    if (tid >= 240) return;
+    const int sub = tid / CPC, k = tid - sub * CPC;
+    // per_xcd == 0: one linear front (pass = block); else the first pass of this block inside its XCD's range
+    const int64_t pass0 = per_xcd > 0 ? (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+    const int64_t end = per_xcd > 0 ? ((int64_t)(blockIdx.x & 7) + 1) * per_xcd : pass0 + 1;   // passes of other XCDs are not ours
+    // rows / columns of this thread's chunk (fixed): sizeof(E) >= 2: one row; u8: the 16 elements lie in at most two rows
+    const int ra = (k * EPT) / T::C, rb = sizeof(E) >= 2 ? ra : (k * 16 + 12) / T::C;
+    uint32_t ca[F], cb[F];
+    bool live[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        const int64_t pass = pass0 + f * per_front, cube = pass * CPP + sub;
+        live[f] = pass < end && cube < n && (f == 0 || per_front > 0);
+        ca[f] = cb[f] = 0xff;
+        if (live[f]) {
+            const uint8_t *src = code + tile_off(cube, code_pitch, shift, T::SLOTS);   // row 0 of this cube's code column
+            ca[f] = src[(int64_t)ra * code_pitch];
+            if constexpr (sizeof(E) == 1) cb[f] = src[(int64_t)rb * code_pitch];
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        if (!live[f]) continue;
+        Pk<4> u;
+        if constexpr (sizeof(E) >= 2) {
+            u = onehot_chunk<E>(ca[f] - (uint32_t)(k * EPT - ra * T::C));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = k * 16 + 4 * j, r = e / T::C;
+                const uint32_t d = (r == ra ? ca[f] : cb[f]) - (uint32_t)(e - r * T::C);
+                u.d[j] = d < 4u ? 1u << (8u * d) : 0u;
+            }
+        }
+        // the pass is 3840 contiguous bytes: thread t owns bytes 16 t ..
+        bst<4, RC_DENSE_AUX>(make_srd(dense + (pass0 + f * per_front) * (CPP * 480)), (uint32_t)tid * 16u, 0, u);
     }
 }
 
@@ -969,7 +1031,10 @@ int launch_step(const StepArgs &a, hipStream_t st, int pol) {
     const int64_t blocks = (lanes + BLOCK - 1) / BLOCK;
     RC_GRID(blocks);
     const dim3 g((unsigned)blocks), b(BLOCK);
-    if (pol == 3) hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, 3, BLOCK>), g, b, 0, st, a);
+    if (pol == 4) {
+        if constexpr (MOVE && STORE && CODE) hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, 4, BLOCK>), g, b, 0, st, a);
+        else return fail(RC_EINVAL, "row policy 4 belongs to the workspace route%s");
+    } else if (pol == 3) hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, 3, BLOCK>), g, b, 0, st, a);
     else if (pol == 2) hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, 2, BLOCK>), g, b, 0, st, a);
     else if (pol == 1) hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, 1, BLOCK>), g, b, 0, st, a);
     else hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, 0, BLOCK>), g, b, 0, st, a);
@@ -977,10 +1042,12 @@ int launch_step(const StepArgs &a, hipStream_t st, int pol) {
     return RC_OK;
 }
 
+// keep_code: the compact code is read back by the next launch (workspace route): beyond the resident case it is written with POL 4
 template <class T, bool MOVE, bool STORE, bool CODE>
-int dispatch_step(const StepArgs &a, hipStream_t st, int variant) {
+int dispatch_step(const StepArgs &a, hipStream_t st, int variant, bool keep_code = false) {
     const bool writes = STORE && a.out != nullptr;
-    const StepPlan p = plan_step<T>(a.n, writes, writes && a.out == a.in, CODE, a.done != nullptr, a.reward != nullptr, variant);
+    StepPlan p = plan_step<T>(a.n, writes, writes && a.out == a.in, CODE, a.done != nullptr, a.reward != nullptr, variant);
+    if (keep_code && p.pol != 0) p.pol = 4;
     return p.v == 2 ? launch_step<T, 2, MOVE, STORE, CODE>(a, st, p.pol) : launch_step<T, 1, MOVE, STORE, CODE>(a, st, p.pol);
 }
 
@@ -989,9 +1056,9 @@ int dispatch_step(const StepArgs &a, hipStream_t st, int variant) {
 // (small batches -- MCTS leaves -- stay spread over the chip: 4096 cubes are 64 workgroups).
 // Measured at 1M cubes (tools/microbench.py densetile): 256-cube tiles 5.4 TB/s (f32) / 6.3 TB/s (u8) against
 // 4.9 / 5.4 with 1024-cube tiles -- shorter private write streams per workgroup; the wide form: see k_code_to_dense_wide.
-enum DenseForm { kDense64 = 64, kDense256 = 256, kDenseWide = 960 };
+enum DenseForm { kDense64 = 64, kDense256 = 256, kDenseWide = 960, kDenseFront = 1 };
 template <class T>
-inline DenseForm dense_form(int64_t n, int variant, bool fused) {
+inline DenseForm dense_form(int64_t n, int variant, bool fused, int fmt) {
     const bool wide_ok = T::SIZE == 3 && !fused;   // the wide form exists for code -> dense only: a FUSED wide kernel (every wave
     //   produces a tile, then all sweep 15 tiles) was built and measured in round 3 and lost to the 256-thread form for every
     //   format and group count (bf16 0.62-0.74 against 0.74-0.76: its ~110 workgroups funnel the state traffic and stall the
@@ -1000,8 +1067,18 @@ inline DenseForm dense_form(int64_t n, int variant, bool fused) {
     if (forced == 1) return kDense64;
     if (forced == 2) return kDense256;
     if (forced == 3) return wide_ok ? kDenseWide : kDense256;
+    if (forced == 4) return wide_ok ? kDenseFront : kDense256;
+    if (!fused && wide_ok && fmt == RC_FMT_F32 && n >= ((int64_t)1 << 16)) return kDenseFront;   // 2^16 cubes: 0.80 against 0.67
     if (n < ((int64_t)1 << 17)) return kDense64;
-    return wide_ok ? kDenseWide : kDense256;
+    // large batches, measured at 2^20 cubes on 4 buffers per format (profiles/r04_dense_control.json, fraction of the 8 TB/s peak):
+    //   code -> dense: front 0.89-0.92 (f32) / 0.81-0.83 (16-bit) on EVERY allocation against 0.73-0.91 (wide, placement dependent);
+    //                  u8 keeps the wide form (0.77-0.79 against 0.52-0.54: the front's two byte gathers per 16-byte store)
+    //   fused step   : 16-bit formats 64-cube tiles (0.80-0.82 on every allocation against 0.74-0.82), f32 and u8 256-cube tiles
+    //                  (f32 with a workspace takes the two-launch route instead, step_common)
+    // size sweep 2^15 .. 2^22 (profiles/r04_dense_sizes.json): u8 code -> dense 64-cube tiles up to 2^19 (0.71-0.74 against 0.60-0.71
+    // wide), fused 16-bit 64-cube tiles from 2^19 (below: 256-cube tiles, 0.65-0.74 against 0.63-0.70)
+    if (!fused) return !wide_ok ? kDense256 : fmt != RC_FMT_U8 ? kDenseFront : n >= ((int64_t)1 << 19) ? kDenseWide : kDense64;
+    return T::SIZE == 3 && (fmt == RC_FMT_F16 || fmt == RC_FMT_BF16) && n >= ((int64_t)1 << 19) ? kDense64 : kDense256;
 }
 struct WideGrid { int64_t groups, per; };
 // `variant` thousands field (2 digits, otherwise the expansion's parts): wanted workgroups / 16, for tuning sweeps
@@ -1034,7 +1111,7 @@ int launch_dense_t(const StepArgs &a, void *onehot, int fmt, hipStream_t st) {
 
 template <class T, bool MOVE, bool STORE>
 int launch_dense(const StepArgs &a, void *onehot, int fmt, hipStream_t st, int variant) {
-    switch (dense_form<T>(a.n, variant, true)) {
+    switch (dense_form<T>(a.n, variant, true, fmt)) {
         case kDense64: return launch_dense_t<T, MOVE, STORE, 64>(a, onehot, fmt, st);
         default: return launch_dense_t<T, MOVE, STORE, 256>(a, onehot, fmt, st);
     }
@@ -1052,6 +1129,46 @@ int launch_code_to_dense(const uint8_t *code, int64_t n, int64_t code_pitch, int
     else hipLaunchKernelGGL((k_code_to_dense<T, float, TILE>), g, b, 0, st, code, n, code_pitch, sh, static_cast<float *>(onehot));
     RC_HIP(hipGetLastError());
     return RC_OK;
+}
+
+// fronts per XCD of the front writer (kernel comment): units digit of `variant` 1, 2, 4 force it; tens digit 2 = one linear front
+template <class T, int F>
+int launch_front_f(const uint8_t *code, int64_t n, int64_t code_pitch, int sh, void *onehot, int fmt, hipStream_t st, bool linear) {
+    const int cpp = fmt == RC_FMT_F32 ? 2 : fmt == RC_FMT_U8 ? 8 : 4;                // cubes per 3840-byte pass
+    const int64_t passes = (n + cpp - 1) / cpp;
+    int64_t per_xcd = 0, per_front = 0, blocks = passes;
+    if (!linear) {
+        per_front = (passes + 8 * F - 1) / (8 * F);                                  // passes of one front
+        per_xcd = per_front * F;
+        blocks = per_front * 8;
+    }
+    RC_GRID(blocks);
+    const dim3 g((unsigned)blocks), b(256);
+    if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_code_to_dense_front<T, uint8_t, F>), g, b, 0, st, code, n, code_pitch, sh, static_cast<uint8_t *>(onehot), per_xcd, per_front);
+    else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_code_to_dense_front<T, uint16_t, F>), g, b, 0, st, code, n, code_pitch, sh, static_cast<uint16_t *>(onehot), per_xcd, per_front);
+    else if (fmt == RC_FMT_BF16) hipLaunchKernelGGL((k_code_to_dense_front<T, Bf16, F>), g, b, 0, st, code, n, code_pitch, sh, static_cast<Bf16 *>(onehot), per_xcd, per_front);
+    else hipLaunchKernelGGL((k_code_to_dense_front<T, float, F>), g, b, 0, st, code, n, code_pitch, sh, static_cast<float *>(onehot), per_xcd, per_front);
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+inline int front_fronts(int fmt, int variant) {
+    const int v = variant % 10;
+    if (v == 1 || v == 2 || v == 4) return v;
+    (void)fmt;
+    return 1;
+}
+template <class T>
+int launch_code_to_dense_front(const uint8_t *code, int64_t n, int64_t code_pitch, int sh, void *onehot, int fmt, hipStream_t st, int variant) {
+    if constexpr (T::SIZE == 3) {
+        const bool linear = (variant / 10) % 10 == 2;
+        switch (linear ? 1 : front_fronts(fmt, variant)) {
+            case 4: return launch_front_f<T, 4>(code, n, code_pitch, sh, onehot, fmt, st, linear);
+            case 2: return launch_front_f<T, 2>(code, n, code_pitch, sh, onehot, fmt, st, linear);
+            default: return launch_front_f<T, 1>(code, n, code_pitch, sh, onehot, fmt, st, linear);
+        }
+    } else {
+        return launch_code_to_dense<T, 256>(code, n, code_pitch, sh, onehot, fmt, st);
+    }
 }
 
 template <class T>
@@ -1193,7 +1310,7 @@ int launch_adi(AdiArgs a, hipStream_t st) {
 // =============================================================================== C ABI
 extern "C" {
 
-int rc_version(void) { return 300; }
+int rc_version(void) { return 400; }
 
 const char *rc_last_error(void) { return t_err; }
 
@@ -1245,9 +1362,20 @@ int rc_fill_solved(uint8_t *stp, int64_t n, int64_t pitch, int cube_size, void *
     });
 }
 
+// Two-launch dense route (rc_apply_moves_ws): the step kernel writes the compact code into the caller's workspace (one tile,
+// [SLOTS][ws_pitch]), the front writer expands it.  3x3x3 only, from kFrontMin cubes; 0 = not applicable.
+// Measured at 2^20 cubes on 4 buffers per format (profiles/r04_dense_control.json): f32 0.84-0.89 of peak on every allocation against
+// 0.70 / 0.86 (placement dependent) for the one-launch kernel.  The 1- and 2-byte formats gain nothing over their one-launch kernels
+// (bf16: 0.79-0.82 against 0.80-0.82 with 64-cube tiles; u8: 0.69 against 0.81) and have no use for a workspace.
+constexpr int64_t kFrontMin = (int64_t)1 << 17, kWsTile = 32768;     // the workspace is tiled like every code buffer: [tile][SLOTS][32768]
+inline int64_t dense_workspace_bytes(int cube_size, int64_t n, int fmt) {
+    if (cube_size != 3 || fmt != RC_FMT_F32 || n < kFrontMin) return 0;
+    return (n + kWsTile - 1) / kWsTile * kWsTile * 20;
+}
+
 static int step_common(const uint8_t *in, uint8_t *out, const uint8_t *actions, int64_t n, int64_t pitch_in, int64_t pitch_out,
                        int cube_size, float *reward, uint8_t *done, void *onehot, int fmt, int64_t code_pitch, void *stream,
-                       bool move, bool store, int variant) {
+                       bool move, bool store, int variant, void *workspace = nullptr, int64_t workspace_bytes = 0) {
     RC_NEED_INIT();
     const int sh_in = tile_shift(pitch_in, n), sh_out = store ? tile_shift(pitch_out, n) : 63;
     int sh_code = 63;
@@ -1263,6 +1391,19 @@ static int step_common(const uint8_t *in, uint8_t *out, const uint8_t *actions, 
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
         if (fmt >= RC_FMT_U8) {
+            if constexpr (T::SIZE == 3) {
+                const int64_t need = dense_workspace_bytes(3, n, fmt);
+                if (move && workspace && need > 0 && workspace_bytes >= need && (variant / 100000) % 10 == 0) {
+                    // step + reward + done + compact code (into the workspace), then the front writer: the dense stream leaves as
+                    // one sweeping window instead of thousands of private 240-KiB streams (k_code_to_dense_front)
+                    StepArgs a2 = a;
+                    a2.code = static_cast<uint8_t *>(workspace);
+                    a2.code_pitch = kWsTile;
+                    a2.sh_code = 15;                                                 // log2(kWsTile)
+                    if (int rc = dispatch_step<T, true, true, true>(a2, st, variant, true)) return rc;
+                    return launch_code_to_dense_front<T>(a2.code, n, a2.code_pitch, a2.sh_code, onehot, fmt, st, 0);
+                }
+            }
             if (move) return launch_dense<T, true, true>(a, onehot, fmt, st, variant);
             return launch_dense<T, false, false>(a, onehot, fmt, st, variant);
         }
@@ -1283,6 +1424,20 @@ int rc_apply_moves_ex(const uint8_t *in, uint8_t *out, const uint8_t *actions, i
 int rc_apply_moves(const uint8_t *in, uint8_t *out, const uint8_t *actions, int64_t n, int64_t pitch_in, int64_t pitch_out,
                    int cube_size, float *reward, uint8_t *done, void *onehot, int fmt, int64_t code_pitch, void *stream) {
     return step_common(in, out, actions, n, pitch_in, pitch_out, cube_size, reward, done, onehot, fmt, code_pitch, stream, true, true, 0);
+}
+
+int64_t rc_workspace_bytes(int op, int cube_size, int64_t n, int fmt) {
+    if (op != RC_OP_STEP || n <= 0) return 0;
+    return dense_workspace_bytes(cube_size, n, fmt);
+}
+
+int rc_apply_moves_ws(const uint8_t *in, uint8_t *out, const uint8_t *actions, int64_t n, int64_t pitch_in, int64_t pitch_out,
+                      int cube_size, float *reward, uint8_t *done, void *onehot, int fmt, int64_t code_pitch, void *workspace,
+                      int64_t workspace_bytes, void *stream) {
+    if (workspace && !aligned16(workspace)) return fail(RC_EINVAL, "workspace must be 16-byte aligned%s");
+    if (workspace_bytes < 0) return fail(RC_EINVAL, "workspace_bytes is negative%s");
+    return step_common(in, out, actions, n, pitch_in, pitch_out, cube_size, reward, done, onehot, fmt, code_pitch, stream, true, true, 0,
+                       workspace, workspace_bytes);
 }
 
 int rc_scramble(uint8_t *stp, int64_t n, int64_t pitch, int cube_size, int depth, uint64_t seed, uint64_t stream_id,
@@ -1340,7 +1495,8 @@ int rc_onehot_from_code_ex(const uint8_t *code, int64_t n, int64_t code_pitch, i
     if (n == 0) return RC_OK;
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
-        switch (dense_form<T>(n, variant, false)) {
+        switch (dense_form<T>(n, variant, false, fmt)) {
+            case kDenseFront: return launch_code_to_dense_front<T>(code, n, code_pitch, sh, onehot, fmt, S(stream), variant);
             case kDenseWide: return launch_code_to_dense_wide<T>(code, n, code_pitch, sh, onehot, fmt, S(stream), variant);
             case kDense256: return launch_code_to_dense<T, 256>(code, n, code_pitch, sh, onehot, fmt, S(stream));
             default: return launch_code_to_dense<T, 64>(code, n, code_pitch, sh, onehot, fmt, S(stream));
@@ -1525,7 +1681,15 @@ int rc_describe_dispatch(int op, int cube_size, int64_t n, int depth, unsigned o
         if (op == RC_OP_STEP) {
             if (fmt >= RC_FMT_U8 && fmt <= RC_FMT_BF16) {
                 static const char *const names[] = {"", "", "u8", "f16", "f32", "bf16"};
-                const int form = (int)dense_form<T>(n, variant, true);
+                if ((outputs & RC_OUT_WORKSPACE) && states && dense_workspace_bytes(T::SIZE, n, fmt) > 0 && (variant / 100000) % 10 == 0) {
+                    StepPlan p = plan_step<T>(n, true, outputs & RC_OUT_INPLACE, true, outputs & RC_OUT_DONE, outputs & RC_OUT_REWARD, variant);
+                    if (p.pol != 0) p.pol = 4;
+                    const int cpp = fmt == RC_FMT_F32 ? 2 : fmt == RC_FMT_U8 ? 8 : 4, F = front_fronts(fmt, 0);
+                    snprintf(buf, buflen, "k_step<%s,V=%d,move,store,code,POL=%d> grid=%lld block=64 + k_code_to_dense_front<%s,%s,F=%d> xcd grid=%lld block=256", cube, p.v,
+                             p.pol, (long long)((n + 256 * p.v - 1) / (256 * p.v)), cube, names[fmt], F, (long long)(((n + cpp - 1) / cpp + 8 * F - 1) / (8 * F) * 8));
+                    return RC_OK;
+                }
+                const int form = (int)dense_form<T>(n, variant, true, fmt);
                 snprintf(buf, buflen, "k_step_dense<%s,%s,%s,TILE=%d> grid=%lld block=%d", cube, names[fmt], states ? "move,store" : "encode",
                          form, (long long)dense_grid((n + form - 1) / form, fmt), kDenseBlock);
                 return RC_OK;
@@ -1539,8 +1703,14 @@ int rc_describe_dispatch(int op, int cube_size, int64_t n, int depth, unsigned o
         if (op == RC_OP_CODE_TO_DENSE) {
             static const char *const names[] = {"", "", "u8", "f16", "f32", "bf16"};
             if (fmt < RC_FMT_U8 || fmt > RC_FMT_BF16) return fail(RC_EINVAL, "rc_describe_dispatch: dense fmt required%s");
-            const DenseForm form = dense_form<T>(n, variant, false);
-            if (form == kDenseWide) {
+            const DenseForm form = dense_form<T>(n, variant, false, fmt);
+            if (form == kDenseFront) {
+                const int cpp = fmt == RC_FMT_F32 ? 2 : fmt == RC_FMT_U8 ? 8 : 4;
+                const bool xcd = (variant / 10) % 10 != 2;
+                const int F = xcd ? front_fronts(fmt, variant) : 1;
+                snprintf(buf, buflen, "k_code_to_dense_front<%s,%s,F=%d> cubes_per_pass=%d%s grid=%lld block=256", cube, names[fmt], F, cpp, xcd ? " xcd" : "",
+                         (long long)(xcd ? ((n + cpp - 1) / cpp + 8 * F - 1) / (8 * F) * 8 : (n + cpp - 1) / cpp));
+            } else if (form == kDenseWide) {
                 const WideGrid w = wide_grid(n, variant);
                 snprintf(buf, buflen, "k_code_to_dense_wide<%s,%s> tiles_per_group=%lld grid=%lld block=%d", cube, names[fmt], (long long)w.per, (long long)w.groups, kWideBlock);
             } else {

@@ -123,8 +123,25 @@ def _onehot_args(onehot, fmt, n, cube_size, what):
     return onehot, 0
 
 
+_workspaces = {}     # (device index, stream handle) -> uint8 tensor; grown on demand, never shared between streams
+
+
+def workspace(device, nbytes):
+    """Scratch tensor for rc_apply_moves_ws on `device`'s CURRENT stream (the library allocates nothing: the caller owns it).
+    One per (device, stream): launches of one stream are ordered, so reusing it between calls is safe."""
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream_ptr(device).value)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
 def apply_moves(src, dst, actions, n, cube_size, reward=None, done=None, onehot=None, fmt=FMT_NONE, variant=0):
     """CubeEnv.step for n cubes (cube_env.py:71-111).  dst may be src (in place).
+    A dense `onehot` on a large 3x3x3 batch goes through rc_apply_moves_ws with a cached workspace (two launches: step + compact
+    code, then the front writer: same results, the dense stream at 0.8-0.94 of the HBM peak wherever the buffer lives).
     variant: per-call tuning override (include/rubikhip.h "Tuning override"; tests and benchmarks only)."""
     S, _, _ = _size(cube_size)
     p_in, p_out = _tiled(src, S, n, "apply_moves src"), _tiled(dst, S, n, "apply_moves dst")
@@ -136,6 +153,12 @@ def apply_moves(src, dst, actions, n, cube_size, reward=None, done=None, onehot=
     if variant:
         check(lib().rc_apply_moves_ex(ptr(src), ptr(dst), ptr(actions), n, p_in, p_out, cube_size, ptr(reward), ptr(done),
                                       ptr(oh), fmt, cp, stream_ptr(src.device), variant))
+        return
+    need = lib().rc_workspace_bytes(_lib.OP_STEP, cube_size, n, fmt) if fmt >= _lib.FMT_U8 else 0
+    if need > 0:
+        ws = workspace(src.device, need)
+        check(lib().rc_apply_moves_ws(ptr(src), ptr(dst), ptr(actions), n, p_in, p_out, cube_size, ptr(reward), ptr(done),
+                                      ptr(oh), fmt, cp, ptr(ws), ws.numel(), stream_ptr(src.device)))
         return
     check(lib().rc_apply_moves(ptr(src), ptr(dst), ptr(actions), n, p_in, p_out, cube_size, ptr(reward), ptr(done),
                                ptr(oh), fmt, cp, stream_ptr(src.device)))

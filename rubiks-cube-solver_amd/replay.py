@@ -48,7 +48,9 @@ class TensorReplayBuffer(Dataset):
         self.error_memory = np.zeros(cap, dtype=np.float64)          # host: the sampling probabilities are drawn there
         self._start, self._count = 0, 0
         self.prioritized_idx = None
-        self._dense = None                                           # uint8 [len(prioritized_idx), R, C] of the current sample
+        self._dense = None                                           # uint8 [len(prioritized_idx), R, C] of the current sample, a CACHE:
+        #   dropped by every append (the ring may move under the logical indices), rebuilt on the next read, so a state always
+        #   comes from the same live entry as its targets -- what the reference's deque gives (utils.py:226-243)
 
     # ------------------------------------------------------------------ deque bookkeeping
     def _phys(self, logical):
@@ -74,6 +76,7 @@ class TensorReplayBuffer(Dataset):
         self.target_policy[idx] = tp.to(self.device, torch.int64)
         self.scramble_count[idx] = sc.to(self.device, torch.int64)
         self.error_memory[(first + np.arange(m)) % cap] = err
+        self._dense = None                                           # logical indices may now name other entries
         over = self._count + m - cap
         if over > 0:
             self._start = (self._start + over) % cap
@@ -124,13 +127,18 @@ class TensorReplayBuffer(Dataset):
         ops.onehot_from_code(soa, b, self.cube_size, dense)
         return dense
 
+    def _sample_dense(self):
+        if self._dense is None:
+            self._dense = self._expand(self.prioritized_idx)
+        return self._dense
+
     def __len__(self):
         return len(self.prioritized_idx)
 
     def __getitem__(self, idx):
         memory_idx = int(self.prioritized_idx[idx])
         p = self._phys(memory_idx)
-        state = self._dense[idx].to(torch.int64 if self.cube_size == 3 else torch.float64)   # py333.py:238 / cube_env.py:143
+        state = self._sample_dense()[idx].to(torch.int64 if self.cube_size == 3 else torch.float64)   # py333.py:238 / cube_env.py:143
         return (state, self.target_value[p], self.target_policy[p], self.scramble_count[p],
                 torch.tensor(memory_idx, device=self.device))
 
@@ -153,10 +161,11 @@ class TensorReplayBuffer(Dataset):
         phys_all = torch.from_numpy(self._phys(np.asarray(self.prioritized_idx, dtype=np.int64))).to(self.device)
         # the DataLoader itself walks an index-only view of this buffer: same sampler, same draws from torch's generator
         order = DataLoader(_Indices(len(self)), batch_size=batch_size, shuffle=shuffle, collate_fn=lambda b: torch.as_tensor(b, dtype=torch.int64))
+        dense = self._sample_dense()
         for i in order:
             d = i.to(self.device)
             p = phys_all[d]
-            yield (self._dense[d].to(dtype), self.target_value[p], self.target_policy[p], self.scramble_count[p], mem[i].to(self.device))
+            yield (dense[d].to(dtype), self.target_value[p], self.target_policy[p], self.scramble_count[p], mem[i].to(self.device))
 
 
 class _Indices(Dataset):

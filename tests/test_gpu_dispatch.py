@@ -469,6 +469,72 @@ def test_outputs_beyond_4gib_adi_and_expansion(ops, L, oracle):
     assert L.read_status() == 0
 
 
+@pytest.mark.parametrize("n", [1, 7, 3841, 70001, (1 << 17) + 77, 300_001])
+def test_dense_front_forms_and_workspace_route(ops, L, oracle, n):
+    """Round 4's FRONT writer (one 3840-byte pass per workgroup: 2 / 4 / 8 whole cubes) in every shape -- one linear front, one
+    front per XCD, 2 and 4 fronts per XCD -- x every element type, on ragged sizes (a last pass with 1 .. 7 cubes, XCD ranges of
+    unequal length, grids padded to a multiple of 8), from tiled and single-tile code buffers; and the two-launch route of
+    rc_apply_moves_ws (step + compact code into the caller's workspace, then the front writer), ping-pong and in place, against
+    the one-launch kernel and the oracle (py333.py:220-246, cube_env.py:71-111)."""
+    cs = 3
+    states = walk_states(oracle, cs, n, 12, seed=n % 1000 + 1)
+    acts = np.random.default_rng(n + 1).integers(0, 12, n, dtype=np.uint8)
+    k = min(n, 64)
+    states[:k] = oracle.step(cs, oracle.solved(cs, k), acts[:k] ^ 1)[0]                  # these become solved
+    exp_st, exp_code, exp_done, exp_rew = oracle.step(cs, states, acts, threads=8)
+    src = ops.from_aos(states, "cuda")
+    a_d = torch.from_numpy(acts).cuda()
+    exp_code_t = torch.from_numpy(exp_code).cuda()
+    fmts = ((L.FMT_U8, torch.uint8), (L.FMT_F16, torch.float16), (L.FMT_BF16, torch.bfloat16), (L.FMT_F32, torch.float32))
+    for pitch in (None, L.pitch_for(n)):                                                  # 32768-cube tiles / one tile
+        code_buf = ops.alloc_code(n, cs, "cuda", pitch=pitch)
+        ops.encode(src, n, cs, code_buf, L.FMT_CODE)
+        src_code = ops.to_aos(code_buf, n)
+        for form in (400000, 400001, 400002, 400004, 400020):
+            for fmt, dt in fmts:
+                oh = torch.full((n + 3, 20, 24), 3, dtype=dt, device="cuda")            # three guard cubes behind the batch
+                ops.onehot_from_code(code_buf, n, cs, oh[:n], variant=form)
+                tag = (n, pitch, form, str(dt))
+                assert torch.equal(oh[:n].float().argmax(-1).to(torch.uint8), src_code), tag
+                assert float(oh[:n].float().sum()) == 20.0 * n and float(oh[:n].float().max()) == 1.0, tag
+                assert float(oh[n:].float().min()) == 3.0 and float(oh[n:].float().max()) == 3.0, tag     # nothing written past the batch
+    # the workspace route (float32, from 2^17 cubes; smaller batches and other formats must take the one-launch kernel unchanged)
+    lib = L.lib()
+    for fmt, dt in fmts:
+        need = lib.rc_workspace_bytes(L.OP_STEP, cs, n, fmt)
+        assert (need > 0) == (fmt == L.FMT_F32 and n >= 1 << 17), (n, fmt, need)
+        oh = torch.full((n, 20, 24), 3, dtype=dt, device="cuda")
+        dst = torch.zeros_like(src)
+        rew = torch.zeros(n, dtype=torch.float32, device="cuda")
+        done = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
+        ops.apply_moves(src, dst, a_d, n, cs, rew, done, oh, fmt)                         # default dispatch: with a workspace where one is used
+        tag = (n, "ws" if need else "one launch", str(dt))
+        assert torch.equal(oh.float().argmax(-1).to(torch.uint8), exp_code_t) and float(oh.float().sum()) == 20.0 * n, tag
+        assert (ops.to_aos(dst, n).cpu().numpy() == exp_st).all(), tag
+        assert (done.cpu().numpy() == exp_done).all() and (rew.cpu().numpy() == exp_rew).all(), tag
+        if need:
+            ref = torch.full((n, 20, 24), 3, dtype=dt, device="cuda")
+            dst2 = torch.zeros_like(src)
+            ops.apply_moves(src, dst2, a_d, n, cs, rew, done, ref, fmt, variant=200000)   # the one-launch kernel
+            assert torch.equal(ref, oh) and torch.equal(dst2, dst), tag
+            work = src.clone()
+            oh.fill_(3)
+            ops.apply_moves(work, work, a_d, n, cs, None, done, oh, fmt)                  # in place, with the workspace
+            assert torch.equal(work, dst) and torch.equal(ref, oh), tag
+            # a workspace that is too small (or NULL) falls back to the one-launch kernel: same results
+            ws = torch.empty(need - 16, dtype=torch.uint8, device="cuda")
+            oh.fill_(3)
+            p_in, p_out = src.shape[-1], dst2.shape[-1]
+            L.check(lib.rc_apply_moves_ws(L.ptr(src), L.ptr(dst2), L.ptr(a_d), n, p_in, p_out, cs, L.ptr(rew), L.ptr(done), L.ptr(oh), fmt, 0,
+                                          L.ptr(ws), ws.numel(), L.stream_ptr(src.device)))
+            assert torch.equal(ref, oh), tag
+            oh.fill_(3)
+            L.check(lib.rc_apply_moves_ws(L.ptr(src), L.ptr(dst2), L.ptr(a_d), n, p_in, p_out, cs, L.ptr(rew), L.ptr(done), L.ptr(oh), fmt, 0,
+                                          None, 0, L.stream_ptr(src.device)))
+            assert torch.equal(ref, oh), tag
+    assert L.read_status() == 0
+
+
 def test_dense_outputs_beyond_4gib(ops, L):
     """Dense one-hot streams larger than 4 GiB: 2^22 cubes as float32 (8 GB) through the wide code -> dense writer and through the
     fused step; every cube's arg-max against the compact code of the same states, one 1 per row (py333.py:235-246)."""

@@ -990,6 +990,44 @@ def test_tensor_replay_buffer_222_and_wraparound():
             assert int(mi) == int(i) and rb.error_memory[rb._phys(int(i))] == smp["error"]
 
 
+def test_tensor_replay_buffer_append_between_sampling_and_reading():
+    """The reference reads state AND targets from the same deque entry at __getitem__ time (utils.py:226-243), so an append
+    between get_prioritized_sample() and the reads -- which shifts a full deque under the logical indices -- still returns
+    consistent samples.  The tensor ring does the same: the dense cache is dropped by every append."""
+    from collections import deque
+    import rubiks_cube_solver_amd as rc
+
+    class Stub(torch.nn.Module):
+        def forward(self, x):
+            if x.dim() == 2:
+                x = x.unsqueeze(0)
+            f = x.reshape(x.shape[0], -1).float().cpu()
+            return (f @ torch.linspace(-0.2, 0.3, f.shape[1]) + 0.01).unsqueeze(-1), torch.zeros(x.shape[0], 12)
+
+    env = rc.make_env(torch.device("cpu"), 3)
+    cap = 40
+    ref, rb = deque(maxlen=cap), rc.TensorReplayBuffer(cap, 12, cube_size=3, device="cuda")
+    for seed, (depth, cubes) in enumerate(((6, 6), (5, 3))):                       # 36 samples, then 15 more: the ring wraps by 11
+        np.random.seed(seed)
+        env.get_random_samples(ref, Stub(), depth, cubes, 0.5)
+        np.random.seed(seed)
+        env.get_random_samples(rb, Stub(), depth, cubes, 0.5)
+        if seed == 0:
+            np.random.seed(5)
+            idx = rb.get_prioritized_sample().copy()                                # sampled BEFORE the second append
+    assert rb.size == cap == len(ref)
+    got = list(rb.batches(5, shuffle=False, dtype=torch.int64))
+    flat = [torch.cat([b[k] for b in got]).cpu().numpy() for k in range(5)]
+    for j, i in enumerate(idx):
+        smp = ref[int(i)]                                                           # the reference: the entry that index names NOW
+        st, tv, tp, sc, mi = rb[j]
+        assert (st.cpu().numpy() == smp["state"]).all() and float(tv) == np.float32(smp["target_value"])
+        assert int(tp) == smp["target_policy"] and int(sc) == smp["scramble_count"] and int(mi) == int(i)
+        assert (flat[0][j] == smp["state"]).all() and flat[1][j] == np.float32(smp["target_value"]) and flat[2][j] == smp["target_policy"]
+    rb.update(idx, np.arange(len(idx)) + 0.5)                                       # update() names the same live entries
+    assert [rb.error_memory[rb._phys(int(i))] for i in idx] == [k + 0.5 for k in range(len(idx))]
+
+
 def test_adi_samples_feeds_the_net_in_its_own_dtype(mod):
     """adi_samples writes the dense one-hot stream in the dtype the value net computes in (a bfloat16 net gets bfloat16
     one-hots: half the bytes of the 13 x walks x 480 elements per depth); the samples are those of the float32 route up to the

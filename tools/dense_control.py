@@ -56,6 +56,57 @@ def build(jobs=4):
     print("built", sorted(os.listdir(CTL)))
 
 
+def sizes():
+    """Every dense form of the shipped library over batch sizes (two output buffers each): where do the defaults belong?"""
+    import torch
+    from rubiks_cube_solver_amd import _lib, ops
+    dev = torch.device("cuda", 0)
+    L = _lib.lib()
+    _lib.init(dev)
+    sp = _lib.stream_ptr(dev)
+
+    def timeit(fn, iters=10, warm=3, reps=3):
+        vals = []
+        for _ in range(reps):
+            for _ in range(warm):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            vals.append(e0.elapsed_time(e1) / iters * 1e3)
+        return sorted(vals)[len(vals) // 2]
+
+    for log2n in (15, 16, 17, 18, 19, 20, 21, 22):
+        for n in ((1 << log2n), (1 << log2n) + (1 << (log2n - 1)) + 1234) if log2n in (17, 19) else ((1 << log2n),):
+            st = ops.alloc_states(n, 3, dev)
+            st2 = torch.empty_like(st)
+            ops.fill_solved(st, n, 3)
+            ops.scramble(st, n, 3, 20, seed=1234)
+            code = ops.alloc_code(n, 3, dev)
+            ops.encode(st, n, 3, code, _lib.FMT_CODE)
+            acts = torch.randint(0, 12, (n,), dtype=torch.uint8, device=dev)
+            rew = torch.empty(n, dtype=torch.float32, device=dev)
+            done = torch.empty(n, dtype=torch.uint8, device=dev)
+            for name, dt, fmt, bpc in (("bf16", torch.bfloat16, _lib.FMT_BF16, 960), ("f32", torch.float32, _lib.FMT_F32, 1920), ("u8", torch.uint8, _lib.FMT_U8, 480)):
+                for bi in range(2):
+                    oh = torch.empty((n, 20, 24), dtype=dt, device=dev)
+                    row = dict(n=n, fmt=name, buf=bi)
+                    for what, v in (("c2d_default", 0), ("c2d_tile64", 100000), ("c2d_256", 200000), ("c2d_wide", 300000), ("c2d_front", 400000)):
+                        t = timeit(lambda: ops.onehot_from_code(code, n, 3, oh, variant=v))
+                        row[what] = round((bpc + 20) * n / (t * 1e-6) / 8e12, 3)
+                    for what, v in (("fused_default(ws)", 0), ("fused_tile64", 100000), ("fused_256", 200000)):
+                        t = timeit(lambda: ops.apply_moves(st, st2, acts, n, 3, rew, done, oh, fmt, variant=v))
+                        row[what] = round((bpc + 114) * n / (t * 1e-6) / 8e12, 3)
+                    print(json.dumps(row), flush=True)
+                    del oh
+            del st, st2, code
+            torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--build", action="store_true")
@@ -63,9 +114,12 @@ def main():
     ap.add_argument("--pmc", action="store_true")
     ap.add_argument("--buffers", type=int, default=4)
     ap.add_argument("--log2n", type=int, default=20)
+    ap.add_argument("--sizes", action="store_true", help="size sweep 2^15 .. 2^22 of the shipped library's dense forms (dispatch thresholds)")
     args = ap.parse_args()
     if args.build:
         return build()
+    if args.sizes:
+        return sizes()
 
     import torch
     from rubiks_cube_solver_amd import _lib, ops
@@ -80,7 +134,7 @@ def main():
     _lib.init(dev)
     for name in BUILDS:
         path = os.path.join(CTL, f"librubikhip_{name}.so")
-        if os.path.exists(path):
+        if os.path.exists(path) and not args.quick:
             L = ctypes.CDLL(path)
             _lib._declare(L)
             assert L.rc_init(0) == 0
@@ -131,7 +185,7 @@ def main():
         assert rc == 0, L.rc_last_error()
 
     fmts = [("bf16", torch.bfloat16, _lib.FMT_BF16, 960), ("f32", torch.float32, _lib.FMT_F32, 1920)]
-    if not args.quick and not args.pmc:
+    if not args.pmc:
         fmts.append(("u8", torch.uint8, _lib.FMT_U8, 480))
     group_fields = [6, 7, 8, 10, 12, 14, 16, 20, 24, 32]          # wide form: wanted groups / 16 (thousands field of `variant`)
     emit(what="header", n=n, device=torch.cuda.get_device_name(0), libs=sorted(libs), iters=iters, reps=reps)
@@ -148,26 +202,54 @@ def main():
             emit(what="hipMemsetAsync", us=t, frac=frac(t, 0), **common)
             t = timeit(lambda: oh.fill_(1))
             emit(what="torch.fill_", us=t, frac=frac(t, 0), **common)
+            L = libs["shipped"]
+            ws = ops.workspace(dev, max(16, L.rc_workspace_bytes(_lib.OP_STEP, 3, n, fmt)))
+
+            def fused_ws(oh):
+                rc = L.rc_apply_moves_ws(st.data_ptr(), st2.data_ptr(), acts.data_ptr(), n, pin, pout, 3, rew.data_ptr(), done.data_ptr(),
+                                         oh.data_ptr(), fmt, 0, ws.data_ptr(), ws.numel(), sp)
+                assert rc == 0, L.rc_last_error()
+
+            for what, fn, extra in (("c2d_front_xcd (default)", lambda: c2d(L, oh, fmt, 0), 20), ("c2d_front_linear", lambda: c2d(L, oh, fmt, 400020), 20),
+                                    ("c2d_front_xcd F=1", lambda: c2d(L, oh, fmt, 400001), 20), ("c2d_front_xcd F=2", lambda: c2d(L, oh, fmt, 400002), 20),
+                                    ("c2d_front_xcd F=4", lambda: c2d(L, oh, fmt, 400004), 20),
+                                    ("fused_ws: step+code, front (rc_apply_moves_ws)", lambda: fused_ws(oh), 114)):
+                t = timeit(fn)
+                emit(what=what, lib="shipped", us=t, frac=frac(t, extra), **common)
             for lname, L in libs.items():
                 if args.pmc and lname not in ("shipped", "pipe1", "ctrl1_pipe1", "ctrl2_pipe1", "ctrl2_pipe4"):
                     continue
-                t = timeit(lambda: c2d(L, oh, fmt, 0))
+                if args.quick and lname != "shipped":
+                    continue
+                t = timeit(lambda: c2d(L, oh, fmt, 300000))
                 emit(what="c2d_wide112", lib=lname, us=t, frac=frac(t, 20), **common)
                 t = timeit(lambda: c2d(L, oh, fmt, 200000))
                 emit(what="c2d_256thread", lib=lname, us=t, frac=frac(t, 20), **common)
+                t = timeit(lambda: c2d(L, oh, fmt, 100000))
+                emit(what="c2d_tile64", lib=lname, us=t, frac=frac(t, 20), **common)
+                t = timeit(lambda: fused(L, oh, fmt, 100000))
+                emit(what="fused_tile64", lib=lname, us=t, frac=frac(t, 114), **common)
                 t = timeit(lambda: fused(L, oh, fmt, 0))
                 emit(what="fused_step_dense", lib=lname, us=t, frac=frac(t, 114), **common)
-                if args.pmc or (args.quick and lname not in ("shipped", "pipe1")):
+                if args.pmc or args.quick:
                     continue
                 if lname in ("shipped", "pipe1", "ctrl2_pipe4", "ctrl2_pipe1", "pipe8"):
                     for f in group_fields:
                         t = timeit(lambda: c2d(L, oh, fmt, 300000 + f * 1000))
                         emit(what=f"c2d_wide{f * 16}", lib=lname, us=t, frac=frac(t, 20), **common)
-            # correctness of the shipped pipelined loop against the 256-thread / 64-tile forms on this buffer
-            c2d(libs["shipped"], oh, fmt, 0)
+            # correctness on this buffer: every form equals the 64-cube-tile form, the workspace route equals the one-launch kernel
             ref = torch.empty_like(oh)
             c2d(libs["shipped"], ref, fmt, 100000)
-            emit(what="check_wide_equals_tile64", ok=bool(torch.equal(oh.view(torch.uint8), ref.view(torch.uint8))), **common)
+            for what, v in (("front_xcd", 0), ("front_linear", 400020), ("front_F2", 400002), ("front_F4", 400004), ("wide", 300000)):
+                oh.zero_()
+                c2d(libs["shipped"], oh, fmt, v)
+                emit(what=f"check_{what}_equals_tile64", ok=bool(torch.equal(oh.view(torch.uint8), ref.view(torch.uint8))), **common)
+            fused(libs["shipped"], ref, fmt, 0)
+            s_ref, r_ref, d_ref = st2.clone(), rew.clone(), done.clone()
+            oh.zero_(); st2.zero_(); rew.zero_(); done.zero_()
+            fused_ws(oh)
+            emit(what="check_fused_ws_equals_one_launch", ok=bool(torch.equal(oh.view(torch.uint8), ref.view(torch.uint8)) and torch.equal(st2, s_ref)
+                                                                 and torch.equal(rew, r_ref) and torch.equal(done, d_ref)), **common)
             del ref
         del bufs
         torch.cuda.empty_cache()

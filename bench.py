@@ -313,7 +313,8 @@ def _free_port():
 def per_config_summary(configs):
     """Compact per-config table for the `roofline` object: name, kernel, launch time, algorithmic bytes per launch, fraction of the
     8 TB/s peak -- frac = bytes / (launch_us * 1e-6) / 8e12, recomputable from the row alone."""
-    return [{"name": r["short"], "kernel": r["kernel"].split(" grid=")[0], "launch_us": round(r["launch_us"], 2),
+    import re
+    return [{"name": r["short"], "kernel": re.sub(r" (grid|block|tiles_per_group|cubes_per_pass)=\d+", "", r["kernel"]), "launch_us": round(r["launch_us"], 2),
              "bytes": r["roofline"]["algorithmic_bytes_per_launch"], "frac": round(r["roofline"]["frac"], 4)}
             for r in configs["records"]]
 

@@ -330,9 +330,10 @@ def test_dense_writer_forms(ops, L, oracle, n):
     ops.encode(src, n, cs, oh, L.FMT_F32)
     assert torch.equal(oh.argmax(-1).to(torch.uint8), src_code) and float(oh.sum()) == 20.0 * n
     assert L.read_status() == 0
-    if n >= 1 << 17:
+    if n >= 1 << 17:                # what form 0 (the default dispatch) was above: round 4's defaults, the wide form is form 300000
         assert "k_step_dense<Cube3,bf16,move,store,TILE=256>" in L.describe(L.OP_STEP, 3, n, outputs=L.OUT_STATES, fmt=L.FMT_BF16)
-        assert "k_code_to_dense_wide" in L.describe(L.OP_CODE_TO_DENSE, 3, n, fmt=L.FMT_F32)
+        assert "k_code_to_dense_front" in L.describe(L.OP_CODE_TO_DENSE, 3, n, fmt=L.FMT_F32)
+        assert "k_code_to_dense_wide" in L.describe(L.OP_CODE_TO_DENSE, 3, n, fmt=L.FMT_F32, variant=300000)
 
 
 def _random_shapes(seed, count):

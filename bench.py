@@ -273,12 +273,17 @@ def other_configs(torch, ops, _lib, dev, acts):
         seq = np.random.default_rng(0).integers(0, 12, 6000)
         for a_ in seq[:500]:
             env.step(int(a_))
-        t0 = time.perf_counter()
-        for a_ in seq[500:]:
-            env.step(int(a_))
-        dt = (time.perf_counter() - t0) / (len(seq) - 500)
-        out["facade_batch1"] = {"CubeEnv.step_us": dt * 1e6, "steps_per_s": 1 / dt,
-                                "note": "reference: 24.6 us/step on one CPU core (SURVEY.md section 6); rc_facade_step, results via host-mapped memory"}
+        batches = []                                              # wall-clock on a shared host: five batches, median and best
+        for b_ in range(5):
+            t0 = time.perf_counter()
+            for a_ in seq[500 + 1100 * b_:500 + 1100 * (b_ + 1)]:
+                env.step(int(a_))
+            batches.append((time.perf_counter() - t0) / 1100)
+        batches.sort()
+        dt = batches[2]
+        out["facade_batch1"] = {"CubeEnv.step_us": dt * 1e6, "CubeEnv.step_us_best_batch": batches[0] * 1e6, "steps_per_s": 1 / dt,
+                                "note": "median / best of five 1100-step batches; reference: 24.6 us/step on one CPU core (SURVEY.md section 6); "
+                                        "rc_facade_step, results via host-mapped memory"}
         # BASELINE config 1's shape (plumbing): 2x2x2, batch 1, reset(seed, 20) then step() + solved flag, through the same facade
         env2 = rc.make_env(torch.device("cpu"), 2)
         t0 = time.perf_counter()

@@ -141,8 +141,9 @@ int rc_facade_steps(uint8_t *st, int64_t pitch, int cube_size, const uint8_t *ac
 int rc_facade_expand(const uint8_t *st, int64_t pitch, int cube_size, uint8_t *host_out, uint32_t seq,
                      int dense, int wait, void *stream);
 
-/* The facade entry points cache, per calling thread, the device alias of the last host_out they validated.  Call this before
- * freeing a host_out buffer whose address could be reused by memory that is not host-mapped (NULL drops whatever is cached). */
+/* The facade entry points cache, per calling thread, the device alias of the last host_out they validated, keyed on (host
+ * address, current device); a call with seq == 1 (a caller's first use of a buffer) always validates afresh.  Call this before
+ * freeing a host_out buffer (NULL drops whatever is cached); CubeEnv.close() / garbage collection does. */
 int rc_facade_release(const uint8_t *host_out);
 
 /* `depth` moves applied in place to every cube: the scramble loop of CubeEnv.reset

@@ -1266,12 +1266,14 @@ void fill_segments(AdiArgs &a, int segs, double replay) {
 }
 
 // grid of the streaming expansion: hundreds digit of `variant` 1..7 -> 128, 192, 256, 384, 512, 768, 1024 waves; 8 -> not streamed
-inline int64_t expand_stream_grid(int64_t n, bool stickers, bool codes, int variant) {
+// out_bytes = n * S * A of the cube size at hand (1M 2x2x2 parents write 151 MB: below the threshold, they keep k_expand -- the
+// streaming form was only measured on 3x3x3).  A forced `parts` value (thousands field, 1 included) or pack width 1 selects k_expand.
+inline int64_t expand_stream_grid(int64_t out_bytes, bool stickers, bool codes, int variant) {
     static const int table[8] = {0, 128, 192, 256, 384, 512, 768, 1024};
     const int h = (variant / 100) % 10;
-    if (!stickers || codes || h == 8 || (variant % 10) == 1 || (variant / 1000) % 100 > 1) return 0;
+    if (!stickers || codes || h == 8 || (variant % 10) == 1 || (variant / 1000) % 100 >= 1) return 0;
     if (h >= 1 && h <= 7) return table[h];                         // forced (tests reach the kernel with small batches too)
-    return n * 54 * 12 >= ((int64_t)256 << 20) ? kExpandStreamGrid : 0;   // large write-once streams only
+    return out_bytes >= ((int64_t)256 << 20) ? kExpandStreamGrid : 0;   // large write-once streams only
 }
 
 template <class T>
@@ -1523,7 +1525,7 @@ int rc_expand_children_ex(const uint8_t *in, int64_t n, int64_t pitch_in, int cu
         ExpandArgs a{in, n, pitch_in, children, child_solved, child_code, pitch_out, n <= pitch_out ? 1 : (n + pitch_out - 1) / pitch_out,
                      geo.parts, sh_in, sh_out};
         hipStream_t st = S(stream);
-        if (const int64_t grid = expand_stream_grid(n, children != nullptr, child_code != nullptr, variant)) return launch_expand_stream<T>(a, st, grid);
+        if (const int64_t grid = expand_stream_grid(n * T::S * T::A, children != nullptr, child_code != nullptr, variant)) return launch_expand_stream<T>(a, st, grid);
         return geo.v == 2 ? launch_expand<T, 2>(a, st) : launch_expand<T, 1>(a, st);
     });
 }
@@ -1589,16 +1591,22 @@ static int facade_wait(uint8_t *host_out, uint32_t seq, void *stream, const char
 // memory the two addresses are equal, for hipHostRegister'ed memory (e.g. torch with pinned_use_cuda_host_register) they may
 // differ, so the kernel always gets attr.devicePointer.  The (host, device) pair of the last buffer is cached per thread;
 // rc_facade_release drops it (call it before freeing a buffer whose address may be reused by non-pinned memory).
-struct FacadeAlias { const uint8_t *host; uint8_t *dev; };
-static thread_local FacadeAlias t_alias{nullptr, nullptr};
-static int facade_check_host(const uint8_t *host_out, const char *who, uint8_t **dev_alias) {
-    if (host_out == t_alias.host) { *dev_alias = t_alias.dev; return RC_OK; }
+// The cache key is (host address, current device): an alias looked up for one device is never used on another.  A sequence number
+// of 1 (a caller's first use of a buffer: every CubeEnv starts its sequence there) always re-validates, so an address that was
+// freed and handed out again -- pinned or not -- is looked up afresh by its new owner.
+struct FacadeAlias { const uint8_t *host; uint8_t *dev; int device; };
+static thread_local FacadeAlias t_alias{nullptr, nullptr, -1};
+static int facade_check_host(const uint8_t *host_out, uint32_t seq, const char *who, uint8_t **dev_alias) {
+    int device = -1;
+    if (hipGetDevice(&device) != hipSuccess) return fail(RC_ENODEV, "no current HIP device%s");
+    if (host_out == t_alias.host && device == t_alias.device && seq != 1) { *dev_alias = t_alias.dev; return RC_OK; }
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes(&attr, host_out) != hipSuccess || attr.type != hipMemoryTypeHost || attr.devicePointer == nullptr) {
         (void)hipGetLastError();
+        if (host_out == t_alias.host) t_alias = {nullptr, nullptr, -1};
         return fail(RC_EINVAL, "%s: host_out must be host-mapped pinned memory (hipHostMalloc / torch pin_memory)", who);
     }
-    t_alias = {host_out, static_cast<uint8_t *>(attr.devicePointer)};
+    t_alias = {host_out, static_cast<uint8_t *>(attr.devicePointer), device};
     *dev_alias = t_alias.dev;
     return RC_OK;
 }
@@ -1610,7 +1618,7 @@ int rc_facade_steps(uint8_t *stp, int64_t pitch, int cube_size, const uint8_t *a
     if (n_actions < 0 || (n_actions > 0 && !actions)) return fail(RC_EINVAL, "rc_facade_steps: bad action list%s");
     if (seq == 0) return fail(RC_EINVAL, "rc_facade_steps: seq must be non-zero%s");
     uint8_t *dev_out = nullptr;
-    if (int rc = facade_check_host(host_out, "rc_facade_steps", &dev_out)) return rc;
+    if (int rc = facade_check_host(host_out, seq, "rc_facade_steps", &dev_out)) return rc;
     const int rc = by_size(cube_size, [&](auto t) {
         using T = decltype(t);
         int done = 0;
@@ -1649,7 +1657,7 @@ static int facade_wait(uint8_t *host_out, uint32_t seq, void *stream, const char
 }
 
 int rc_facade_release(const uint8_t *host_out) {
-    if (host_out == nullptr || host_out == t_alias.host) t_alias = {nullptr, nullptr};
+    if (host_out == nullptr || host_out == t_alias.host) t_alias = {nullptr, nullptr, -1};
     return RC_OK;
 }
 
@@ -1658,7 +1666,7 @@ int rc_facade_expand(const uint8_t *stp, int64_t pitch, int cube_size, uint8_t *
     if (!stp || !host_out || pitch <= 0 || pitch * 54 >= ((int64_t)1 << 32)) return fail(RC_EINVAL, "rc_facade_expand: bad arguments%s");
     if (seq == 0) return fail(RC_EINVAL, "rc_facade_expand: seq must be non-zero%s");
     uint8_t *dev_out = nullptr;
-    if (int rc = facade_check_host(host_out, "rc_facade_expand", &dev_out)) return rc;
+    if (int rc = facade_check_host(host_out, seq, "rc_facade_expand", &dev_out)) return rc;
     const int rc = by_size(cube_size, [&](auto t) {
         using T = decltype(t);
         hipLaunchKernelGGL((k_facade_expand<T>), dim3(1), dim3(kWave), 0, S(stream), stp, (uint32_t)pitch, dev_out, seq, dense);
@@ -1720,7 +1728,7 @@ int rc_describe_dispatch(int op, int cube_size, int64_t n, int depth, unsigned o
         }
         if (op == RC_OP_EXPAND) {
             const Geometry geo = pick_geometry(n, T::A, variant, states, n * T::S * T::A);
-            if (const int64_t grid = expand_stream_grid(n, states, code, variant)) {
+            if (const int64_t grid = expand_stream_grid(n * T::S * T::A, states, code, variant)) {
                 const int64_t groups = (n + 511) / 512;
                 snprintf(buf, buflen, "k_expand_stream<%s> grid=%lld block=64", cube, (long long)(grid < groups ? grid : groups));
                 return RC_OK;

@@ -274,6 +274,23 @@ class CubeEnv:
             error = abs(value.detach().item() - target_value) * weight
         return target_value, target_policy, error
 
+    def close(self):
+        """Drop the pinned result buffer of the batch-1 entry points and the library's cached device alias of it
+        (rc_facade_release), so that the address can be reused by anyone.  Called on garbage collection too; the env
+        stays usable (the buffer is re-created on the next step)."""
+        fast, self._fast = self._fast, None
+        if fast is not None:
+            try:
+                _lib.lib().rc_facade_release(fast[2])
+            except Exception:  # interpreter shutdown: the library may be gone already
+                pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     # ------------------------------------------------------------------ out of scope: rendering
     def render(self, mode=None):
         raise NotImplementedError("rendering (cube_env.py:113-122) is out of scope of the MI355X env path")

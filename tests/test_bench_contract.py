@@ -56,9 +56,10 @@ def test_bench_json_line():
     adi = [x for x in recs if x["config"].startswith("config 3")][0]
     assert adi["roofline"]["bytes_per_unit"] == 715 and adi["roofline"]["frac"] > 0.6
     assert "hipgraph_serial_step_us" in d["configs"]["config5_mcts_4096_leaves"]
-    # a wall-clock latency on a shared host: informative, not gating (the reference's own batch-1 step is 24.6 us; the facade
-    # measures 11-12 us on an idle box) -- only a gross regression fails
-    assert d["configs"]["facade_batch1"]["CubeEnv.step_us"] < 100 and d["configs"]["facade_batch1"]["config1_2x2x2"]["step_us"] < 100
+    # the facade must stay FASTER than the reference's own batch-1 step (24.6 us on one core; 11-12 us measured
+    # here on an idle box).  Wall-clock on a shared host: the best of five 1100-step batches gates, the median only a gross regression
+    fb = d["configs"]["facade_batch1"]
+    assert fb["CubeEnv.step_us_best_batch"] < 24.6 and fb["CubeEnv.step_us"] < 50 and fb["config1_2x2x2"]["step_us"] < 50, fb
     # kernel names come from the library's dispatch (rc_describe_dispatch), never from literals
     assert r["kernel"].startswith("k_step<Cube3,V=") and "POL=" in r["kernel"] and "grid=" in r["kernel"]
     assert all("grid=" in x["kernel"] for x in recs)

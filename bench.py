@@ -227,8 +227,8 @@ def other_configs(torch, ops, _lib, dev, acts):
         t = timed(lambda: ops.apply_moves(a1, b1, acts, m, CUBE, rew, done, oh, fmt), 10, 2)
         rec(f"1M step+dense {name}", f"3x3x3 batch 1M, apply_move + reward + done + fused dense {name} one-hot [N,20,24]",
             D(_lib.OP_STEP, CUBE, m, outputs=ST | REW | _lib.OUT_WORKSPACE, fmt=fmt), m, "steps", 114 + bpc, t,
-            "ops.apply_moves = rc_apply_moves_ws: one call; float32 runs as two launches (step + compact code into a caller-owned workspace, then "
-            "the front writer), the 16-bit formats as one launch")
+            "ops.apply_moves = rc_apply_moves_ws: ONE call, two launches (step + reward + done + compact code into a caller-owned workspace, "
+            "then the front writer: one 3840-byte pass per workgroup)")
         del oh
     # compact code -> dense one-hot: what adi_samples, the replay sink and the lockstep search launch (the wide writer)
     code1 = ops.alloc_code(m, CUBE, dev)

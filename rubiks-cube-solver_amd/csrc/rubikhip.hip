@@ -333,32 +333,52 @@ __global__ void __launch_bounds__(kWideBlock) k_code_to_dense_wide(const uint8_t
 //     of the buffer, so the code lines a pass needs were fetched into this XCD's L2 by the passes just before it (8 fronts);
 //   * F: every workgroup serves F such fronts per XCD (one pass each, all code bytes loaded before the first store), which
 //     multiplies the bytes in flight per workgroup lifetime without lengthening any front's private stream.
-// No LDS, no barrier: every thread fetches the one code byte (u8: two) its chunk depends on straight from the code rows.
 // (Wave-uniform scalar loads of the rows + a select chain were tried and lost: 0.64 against 0.81, bf16.)
-template <class T, class E, int F>
+template <class T, class E, int F, bool LDS>
 __global__ void __launch_bounds__(256) k_code_to_dense_front(const uint8_t *__restrict__ code, int64_t n, int64_t code_pitch, int shift, E *__restrict__ dense,
                                                              int64_t per_xcd, int64_t per_front) {
     static_assert(T::SIZE == 3);
     constexpr int EPT = 16 / (int)sizeof(E), CPC = 480 / EPT, CPP = 240 / CPC;   // elements per chunk, chunks per cube, cubes per pass
+    constexpr int WORDS = CPP > 4 ? 2 : 1;                                       // dwords of one code row that hold a pass's cubes
+    // LDS: the pass's code bytes are SLOTS x WORDS aligned dwords fetched by the first lanes of wave 0 (one load instruction, 20
+    // lines) and handed over through LDS, instead of one byte gather per lane in every wave (4 x ~21 lines for the 1- and 2-byte
+    // formats).  f32 passes hold 2 cubes (a wave's gather touches ~11 lines) and run faster WITHOUT the barrier: measured side by
+    // side (profiles/r04_dense_control.json "front_code_fetch"): f32 0.95 gather / 0.87 LDS, bf16 0.81 / 0.87, u8 0.54 / 0.76.
+    __shared__ uint32_t rows[LDS ? F : 1][T::SLOTS * WORDS];
     const int tid = threadIdx.x;
-    if (tid >= 240) return;
-    const int sub = tid / CPC, k = tid - sub * CPC;
+    const int sub = tid / CPC, k = tid - sub * CPC;                             // (tid >= 240: sub == CPP, no chunk)
     // per_xcd == 0: one linear front (pass = block); else the first pass of this block inside its XCD's range
     const int64_t pass0 = per_xcd > 0 ? (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
-    const int64_t end = per_xcd > 0 ? ((int64_t)(blockIdx.x & 7) + 1) * per_xcd : pass0 + 1;   // passes of other XCDs are not ours
     // rows / columns of this thread's chunk (fixed): sizeof(E) >= 2: one row; u8: the 16 elements lie in at most two rows
     const int ra = (k * EPT) / T::C, rb = sizeof(E) >= 2 ? ra : (k * 16 + 12) / T::C;
     uint32_t ca[F], cb[F];
     bool live[F];
+    if constexpr (LDS) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const int64_t cube0 = (pass0 + f * per_front) * CPP, a0 = cube0 & ~(int64_t)3;
+            if (tid < T::SLOTS * WORDS && cube0 < n && (f == 0 || per_front > 0)) {
+                const int r = tid / WORDS, w = tid - r * WORDS;
+                rows[f][tid] = *reinterpret_cast<const uint32_t *>(code + tile_off(a0 + 4 * w, code_pitch, shift, T::SLOTS) + (int64_t)r * code_pitch);
+            }
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int f = 0; f < F; ++f) {
         const int64_t pass = pass0 + f * per_front, cube = pass * CPP + sub;
-        live[f] = pass < end && cube < n && (f == 0 || per_front > 0);
+        live[f] = tid < 240 && cube < n && (f == 0 || per_front > 0);
         ca[f] = cb[f] = 0xff;
         if (live[f]) {
-            const uint8_t *src = code + tile_off(cube, code_pitch, shift, T::SLOTS);   // row 0 of this cube's code column
-            ca[f] = src[(int64_t)ra * code_pitch];
-            if constexpr (sizeof(E) == 1) cb[f] = src[(int64_t)rb * code_pitch];
+            if constexpr (LDS) {
+                const int byte = (int)((pass * CPP) & 3) + sub;                  // the cube's byte inside the row's dword(s)
+                ca[f] = (rows[f][ra * WORDS + (byte >> 2)] >> (8 * (byte & 3))) & 0xffu;
+                if constexpr (sizeof(E) == 1) cb[f] = (rows[f][rb * WORDS + (byte >> 2)] >> (8 * (byte & 3))) & 0xffu;
+            } else {
+                const uint8_t *src = code + tile_off(cube, code_pitch, shift, T::SLOTS);   // row 0 of this cube's code column
+                ca[f] = src[(int64_t)ra * code_pitch];
+                if constexpr (sizeof(E) == 1) cb[f] = src[(int64_t)rb * code_pitch];
+            }
         }
     }
 #pragma unroll
@@ -1068,16 +1088,14 @@ inline DenseForm dense_form(int64_t n, int variant, bool fused, int fmt) {
     if (forced == 2) return kDense256;
     if (forced == 3) return wide_ok ? kDenseWide : kDense256;
     if (forced == 4) return wide_ok ? kDenseFront : kDense256;
-    if (!fused && wide_ok && fmt == RC_FMT_F32 && n >= ((int64_t)1 << 16)) return kDenseFront;   // 2^16 cubes: 0.80 against 0.67
-    if (n < ((int64_t)1 << 17)) return kDense64;
-    // large batches, measured at 2^20 cubes on 4 buffers per format (profiles/r04_dense_control.json, fraction of the 8 TB/s peak):
-    //   code -> dense: front 0.89-0.92 (f32) / 0.81-0.83 (16-bit) on EVERY allocation against 0.73-0.91 (wide, placement dependent);
-    //                  u8 keeps the wide form (0.77-0.79 against 0.52-0.54: the front's two byte gathers per 16-byte store)
-    //   fused step   : 16-bit formats 64-cube tiles (0.80-0.82 on every allocation against 0.74-0.82), f32 and u8 256-cube tiles
-    //                  (f32 with a workspace takes the two-launch route instead, step_common)
-    // size sweep 2^15 .. 2^22 (profiles/r04_dense_sizes.json): u8 code -> dense 64-cube tiles up to 2^19 (0.71-0.74 against 0.60-0.71
-    // wide), fused 16-bit 64-cube tiles from 2^19 (below: 256-cube tiles, 0.65-0.74 against 0.63-0.70)
-    if (!fused) return !wide_ok ? kDense256 : fmt != RC_FMT_U8 ? kDenseFront : n >= ((int64_t)1 << 19) ? kDenseWide : kDense64;
+    // Measured over 2^15 .. 2^22 cubes, two buffers each (profiles/r04_dense_sizes.json, fraction of the 8 TB/s peak):
+    //   code -> dense: the front writer from 2^15 (f32: 0.73 against 0.63), 2^16 (16-bit: 0.69 against 0.65), 2^18 (u8: 0.75 against
+    //                  0.72) cubes -- 0.83-0.95 / 0.77-0.89 / 0.75-0.82 beyond, on every allocation; 64-cube tiles below
+    //   fused step   : (without a workspace; with one see step_common) 64-cube tiles below 2^17 cubes; from there 16-bit formats
+    //                  64-cube tiles from 2^19 (0.78-0.80 against 0.73-0.76), 256-cube tiles otherwise
+    if (!fused && wide_ok && n >= ((int64_t)1 << (fmt == RC_FMT_F32 ? 15 : fmt == RC_FMT_U8 ? 18 : 16))) return kDenseFront;
+    if (n < ((int64_t)1 << 17) || (!fused && wide_ok)) return kDense64;
+    if (!fused) return kDense256;
     return T::SIZE == 3 && (fmt == RC_FMT_F16 || fmt == RC_FMT_BF16) && n >= ((int64_t)1 << 19) ? kDense64 : kDense256;
 }
 struct WideGrid { int64_t groups, per; };
@@ -1131,10 +1149,22 @@ int launch_code_to_dense(const uint8_t *code, int64_t n, int64_t code_pitch, int
     return RC_OK;
 }
 
-// fronts per XCD of the front writer (kernel comment): units digit of `variant` 1, 2, 4 force it; tens digit 2 = one linear front
-template <class T, int F>
-int launch_front_f(const uint8_t *code, int64_t n, int64_t code_pitch, int sh, void *onehot, int fmt, hipStream_t st, bool linear) {
-    const int cpp = fmt == RC_FMT_F32 ? 2 : fmt == RC_FMT_U8 ? 8 : 4;                // cubes per 3840-byte pass
+// Shape of the front writer per format (kernel comment; measured side by side at 2^20 cubes, four buffers each): f32 a byte gather
+// per lane, one front per XCD (0.95); 16-bit wave 0's load + LDS, one front (0.87); u8 LDS, two fronts per XCD per workgroup
+// (0.82-0.86; one front 0.76).  `variant`: units digit 1, 2, 4 force F; tens digit 2 = one linear front, 3 = gather, 4 = LDS.
+struct FrontShape { int f; bool lds, linear; };
+inline FrontShape front_shape(int fmt, int variant) {
+    const int v = variant % 10, t = (variant / 10) % 10;
+    FrontShape s{fmt == RC_FMT_U8 ? 2 : 1, fmt != RC_FMT_F32, t == 2};
+    if (v == 1 || v == 2 || v == 4) s.f = v;
+    if (t == 3) s.lds = false;
+    if (t == 4) s.lds = true;
+    if (s.linear) s.f = 1;
+    return s;
+}
+template <class T, class E, int F, bool LDS>
+int launch_front_e(const uint8_t *code, int64_t n, int64_t code_pitch, int sh, E *onehot, hipStream_t st, bool linear) {
+    constexpr int cpp = 240 / (480 / (16 / (int)sizeof(E)));                        // cubes per 3840-byte pass: 2 / 4 / 8
     const int64_t passes = (n + cpp - 1) / cpp;
     int64_t per_xcd = 0, per_front = 0, blocks = passes;
     if (!linear) {
@@ -1143,29 +1173,29 @@ int launch_front_f(const uint8_t *code, int64_t n, int64_t code_pitch, int sh, v
         blocks = per_front * 8;
     }
     RC_GRID(blocks);
-    const dim3 g((unsigned)blocks), b(256);
-    if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_code_to_dense_front<T, uint8_t, F>), g, b, 0, st, code, n, code_pitch, sh, static_cast<uint8_t *>(onehot), per_xcd, per_front);
-    else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_code_to_dense_front<T, uint16_t, F>), g, b, 0, st, code, n, code_pitch, sh, static_cast<uint16_t *>(onehot), per_xcd, per_front);
-    else if (fmt == RC_FMT_BF16) hipLaunchKernelGGL((k_code_to_dense_front<T, Bf16, F>), g, b, 0, st, code, n, code_pitch, sh, static_cast<Bf16 *>(onehot), per_xcd, per_front);
-    else hipLaunchKernelGGL((k_code_to_dense_front<T, float, F>), g, b, 0, st, code, n, code_pitch, sh, static_cast<float *>(onehot), per_xcd, per_front);
+    hipLaunchKernelGGL((k_code_to_dense_front<T, E, F, LDS>), dim3((unsigned)blocks), dim3(256), 0, st, code, n, code_pitch, sh, onehot, per_xcd, per_front);
     RC_HIP(hipGetLastError());
     return RC_OK;
 }
-inline int front_fronts(int fmt, int variant) {
-    const int v = variant % 10;
-    if (v == 1 || v == 2 || v == 4) return v;
-    (void)fmt;
-    return 1;
+template <class T, class E>
+int launch_front_shape(const uint8_t *code, int64_t n, int64_t code_pitch, int sh, E *onehot, hipStream_t st, FrontShape s) {
+    if (s.lds) {
+        if (s.f == 4) return launch_front_e<T, E, 4, true>(code, n, code_pitch, sh, onehot, st, s.linear);
+        if (s.f == 2) return launch_front_e<T, E, 2, true>(code, n, code_pitch, sh, onehot, st, s.linear);
+        return launch_front_e<T, E, 1, true>(code, n, code_pitch, sh, onehot, st, s.linear);
+    }
+    if (s.f == 4) return launch_front_e<T, E, 4, false>(code, n, code_pitch, sh, onehot, st, s.linear);
+    if (s.f == 2) return launch_front_e<T, E, 2, false>(code, n, code_pitch, sh, onehot, st, s.linear);
+    return launch_front_e<T, E, 1, false>(code, n, code_pitch, sh, onehot, st, s.linear);
 }
 template <class T>
 int launch_code_to_dense_front(const uint8_t *code, int64_t n, int64_t code_pitch, int sh, void *onehot, int fmt, hipStream_t st, int variant) {
     if constexpr (T::SIZE == 3) {
-        const bool linear = (variant / 10) % 10 == 2;
-        switch (linear ? 1 : front_fronts(fmt, variant)) {
-            case 4: return launch_front_f<T, 4>(code, n, code_pitch, sh, onehot, fmt, st, linear);
-            case 2: return launch_front_f<T, 2>(code, n, code_pitch, sh, onehot, fmt, st, linear);
-            default: return launch_front_f<T, 1>(code, n, code_pitch, sh, onehot, fmt, st, linear);
-        }
+        const FrontShape s = front_shape(fmt, variant);
+        if (fmt == RC_FMT_U8) return launch_front_shape<T>(code, n, code_pitch, sh, static_cast<uint8_t *>(onehot), st, s);
+        if (fmt == RC_FMT_F16) return launch_front_shape<T>(code, n, code_pitch, sh, static_cast<uint16_t *>(onehot), st, s);
+        if (fmt == RC_FMT_BF16) return launch_front_shape<T>(code, n, code_pitch, sh, static_cast<Bf16 *>(onehot), st, s);
+        return launch_front_shape<T>(code, n, code_pitch, sh, static_cast<float *>(onehot), st, s);
     } else {
         return launch_code_to_dense<T, 256>(code, n, code_pitch, sh, onehot, fmt, st);
     }
@@ -1366,12 +1396,12 @@ int rc_fill_solved(uint8_t *stp, int64_t n, int64_t pitch, int cube_size, void *
 
 // Two-launch dense route (rc_apply_moves_ws): the step kernel writes the compact code into the caller's workspace (one tile,
 // [SLOTS][ws_pitch]), the front writer expands it.  3x3x3 only, from kFrontMin cubes; 0 = not applicable.
-// Measured at 2^20 cubes on 4 buffers per format (profiles/r04_dense_control.json): f32 0.84-0.89 of peak on every allocation against
-// 0.70 / 0.86 (placement dependent) for the one-launch kernel.  The 1- and 2-byte formats gain nothing over their one-launch kernels
-// (bf16: 0.79-0.82 against 0.80-0.82 with 64-cube tiles; u8: 0.69 against 0.81) and have no use for a workspace.
-constexpr int64_t kFrontMin = (int64_t)1 << 17, kWsTile = 32768;     // the workspace is tiled like every code buffer: [tile][SLOTS][32768]
+// Measured over 2^17 .. 2^22 cubes (profiles/r04_dense_sizes.json): f32 0.78-0.92 of peak on every allocation against 0.63-0.86
+// (placement dependent) for the one-launch kernel, 16-bit formats 0.65-0.85 against 0.62-0.80.  u8 gains nothing while its state
+// ping-pong fits the Infinity Cache (0.80 against 0.81 at 2^20) and takes the route from 2^22 cubes only (0.79 against 0.65).
+constexpr int64_t kFrontMin = (int64_t)1 << 17, kFrontMinU8 = (int64_t)1 << 22, kWsTile = 32768;     // workspace = a tiled code buffer [tile][SLOTS][32768]
 inline int64_t dense_workspace_bytes(int cube_size, int64_t n, int fmt) {
-    if (cube_size != 3 || fmt != RC_FMT_F32 || n < kFrontMin) return 0;
+    if (cube_size != 3 || fmt < RC_FMT_U8 || fmt > RC_FMT_BF16 || n < (fmt == RC_FMT_U8 ? kFrontMinU8 : kFrontMin)) return 0;
     return (n + kWsTile - 1) / kWsTile * kWsTile * 20;
 }
 
@@ -1692,9 +1722,11 @@ int rc_describe_dispatch(int op, int cube_size, int64_t n, int depth, unsigned o
                 if ((outputs & RC_OUT_WORKSPACE) && states && dense_workspace_bytes(T::SIZE, n, fmt) > 0 && (variant / 100000) % 10 == 0) {
                     StepPlan p = plan_step<T>(n, true, outputs & RC_OUT_INPLACE, true, outputs & RC_OUT_DONE, outputs & RC_OUT_REWARD, variant);
                     if (p.pol != 0) p.pol = 4;
-                    const int cpp = fmt == RC_FMT_F32 ? 2 : fmt == RC_FMT_U8 ? 8 : 4, F = front_fronts(fmt, 0);
-                    snprintf(buf, buflen, "k_step<%s,V=%d,move,store,code,POL=%d> grid=%lld block=64 + k_code_to_dense_front<%s,%s,F=%d> xcd grid=%lld block=256", cube, p.v,
-                             p.pol, (long long)((n + 256 * p.v - 1) / (256 * p.v)), cube, names[fmt], F, (long long)(((n + cpp - 1) / cpp + 8 * F - 1) / (8 * F) * 8));
+                    const int cpp = fmt == RC_FMT_F32 ? 2 : fmt == RC_FMT_U8 ? 8 : 4;
+                    const FrontShape fs = front_shape(fmt, 0);
+                    snprintf(buf, buflen, "k_step<%s,V=%d,move,store,code,POL=%d> grid=%lld block=64 + k_code_to_dense_front<%s,%s,F=%d,%s> xcd grid=%lld block=256", cube, p.v,
+                             p.pol, (long long)((n + 256 * p.v - 1) / (256 * p.v)), cube, names[fmt], fs.f, fs.lds ? "lds" : "gather",
+                             (long long)(((n + cpp - 1) / cpp + 8 * fs.f - 1) / (8 * fs.f) * 8));
                     return RC_OK;
                 }
                 const int form = (int)dense_form<T>(n, variant, true, fmt);
@@ -1714,10 +1746,9 @@ int rc_describe_dispatch(int op, int cube_size, int64_t n, int depth, unsigned o
             const DenseForm form = dense_form<T>(n, variant, false, fmt);
             if (form == kDenseFront) {
                 const int cpp = fmt == RC_FMT_F32 ? 2 : fmt == RC_FMT_U8 ? 8 : 4;
-                const bool xcd = (variant / 10) % 10 != 2;
-                const int F = xcd ? front_fronts(fmt, variant) : 1;
-                snprintf(buf, buflen, "k_code_to_dense_front<%s,%s,F=%d> cubes_per_pass=%d%s grid=%lld block=256", cube, names[fmt], F, cpp, xcd ? " xcd" : "",
-                         (long long)(xcd ? ((n + cpp - 1) / cpp + 8 * F - 1) / (8 * F) * 8 : (n + cpp - 1) / cpp));
+                const FrontShape fs = front_shape(fmt, variant);
+                snprintf(buf, buflen, "k_code_to_dense_front<%s,%s,F=%d,%s> cubes_per_pass=%d%s grid=%lld block=256", cube, names[fmt], fs.f, fs.lds ? "lds" : "gather", cpp,
+                         fs.linear ? "" : " xcd", (long long)(fs.linear ? (n + cpp - 1) / cpp : ((n + cpp - 1) / cpp + 8 * fs.f - 1) / (8 * fs.f) * 8));
             } else if (form == kDenseWide) {
                 const WideGrid w = wide_grid(n, variant);
                 snprintf(buf, buflen, "k_code_to_dense_wide<%s,%s> tiles_per_group=%lld grid=%lld block=%d", cube, names[fmt], (long long)w.per, (long long)w.groups, kWideBlock);

@@ -68,9 +68,9 @@ def test_bench_json_line():
     assert "POL=2" in hbm["kernel"] and abs(r["frac_hbm_only"] - hbm["roofline"]["frac"]) < 1e-12 and 0.5 < r["frac_hbm_only"] < 0.95
     assert r["served_by"] == "hbm + infinity cache" and d["config"]["cubes_per_gpu"] == 1 << 22
     assert any("IN PLACE" in x["config"] for x in recs)
-    assert [x for x in recs if "compact code -> dense bf16" in x["config"]][0]["kernel"].startswith("k_code_to_dense_front<Cube3,bf16,F=1>")
+    assert [x for x in recs if "compact code -> dense bf16" in x["config"]][0]["kernel"].startswith("k_code_to_dense_front<Cube3,bf16,F=1,lds>")
     f32 = [x for x in recs if "fused dense f32" in x["config"]][0]
-    assert f32["kernel"].startswith("k_step<Cube3,V=2,move,store,code,POL=0>") and "+ k_code_to_dense_front<Cube3,f32,F=1>" in f32["kernel"]
+    assert f32["kernel"].startswith("k_step<Cube3,V=2,move,store,code,POL=0>") and "+ k_code_to_dense_front<Cube3,f32,F=1,gather>" in f32["kernel"]
     # round 4: the dense one-hot writers no longer depend on where the output buffer lives (front writer / 64-cube tiles)
     for name in ("fused dense f32", "fused dense bf16", "compact code -> dense f32", "compact code -> dense bf16"):
         assert [x for x in recs if name in x["config"]][0]["roofline"]["frac"] > 0.75, name

@@ -332,7 +332,7 @@ def test_dense_writer_forms(ops, L, oracle, n):
     assert L.read_status() == 0
     if n >= 1 << 17:                # what form 0 (the default dispatch) was above: round 4's defaults, the wide form is form 300000
         assert "k_step_dense<Cube3,bf16,move,store,TILE=256>" in L.describe(L.OP_STEP, 3, n, outputs=L.OUT_STATES, fmt=L.FMT_BF16)
-        assert "k_code_to_dense_front" in L.describe(L.OP_CODE_TO_DENSE, 3, n, fmt=L.FMT_F32)
+        assert "k_code_to_dense_front<Cube3,f32,F=1,gather>" in L.describe(L.OP_CODE_TO_DENSE, 3, n, fmt=L.FMT_F32)
         assert "k_code_to_dense_wide" in L.describe(L.OP_CODE_TO_DENSE, 3, n, fmt=L.FMT_F32, variant=300000)
 
 
@@ -473,7 +473,7 @@ def test_outputs_beyond_4gib_adi_and_expansion(ops, L, oracle):
 @pytest.mark.parametrize("n", [1, 7, 3841, 70001, (1 << 17) + 77, 300_001])
 def test_dense_front_forms_and_workspace_route(ops, L, oracle, n):
     """Round 4's FRONT writer (one 3840-byte pass per workgroup: 2 / 4 / 8 whole cubes) in every shape -- one linear front, one
-    front per XCD, 2 and 4 fronts per XCD -- x every element type, on ragged sizes (a last pass with 1 .. 7 cubes, XCD ranges of
+    front per XCD, 2 and 4 fronts per XCD per workgroup, code bytes gathered per lane or fetched once through LDS -- x every element type, on ragged sizes (a last pass with 1 .. 7 cubes, XCD ranges of
     unequal length, grids padded to a multiple of 8), from tiled and single-tile code buffers; and the two-launch route of
     rc_apply_moves_ws (step + compact code into the caller's workspace, then the front writer), ping-pong and in place, against
     the one-launch kernel and the oracle (py333.py:220-246, cube_env.py:71-111)."""
@@ -491,7 +491,8 @@ def test_dense_front_forms_and_workspace_route(ops, L, oracle, n):
         code_buf = ops.alloc_code(n, cs, "cuda", pitch=pitch)
         ops.encode(src, n, cs, code_buf, L.FMT_CODE)
         src_code = ops.to_aos(code_buf, n)
-        for form in (400000, 400001, 400002, 400004, 400020):
+        # units digit: fronts per XCD per workgroup; tens digit: 2 one linear front, 3 byte gather per lane, 4 one load + LDS
+        for form in (400000, 400031, 400032, 400034, 400041, 400042, 400044, 400020):
             for fmt, dt in fmts:
                 oh = torch.full((n + 3, 20, 24), 3, dtype=dt, device="cuda")            # three guard cubes behind the batch
                 ops.onehot_from_code(code_buf, n, cs, oh[:n], variant=form)
@@ -503,7 +504,7 @@ def test_dense_front_forms_and_workspace_route(ops, L, oracle, n):
     lib = L.lib()
     for fmt, dt in fmts:
         need = lib.rc_workspace_bytes(L.OP_STEP, cs, n, fmt)
-        assert (need > 0) == (fmt == L.FMT_F32 and n >= 1 << 17), (n, fmt, need)
+        assert (need > 0) == (fmt != L.FMT_U8 and n >= 1 << 17), (n, fmt, need)       # (u8: from 2^22 cubes, test_dense_outputs_u8_4m_workspace)
         oh = torch.full((n, 20, 24), 3, dtype=dt, device="cuda")
         dst = torch.zeros_like(src)
         rew = torch.zeros(n, dtype=torch.float32, device="cuda")
@@ -559,3 +560,25 @@ def test_dense_outputs_beyond_4gib(ops, L):
             assert torch.equal(blk.argmax(-1).to(torch.uint8), want[lo_:lo_ + (1 << 20)]), (how, lo_)
             assert float(blk.sum()) == 20.0 * blk.shape[0] and float(blk.max()) == 1.0, (how, lo_)
     assert L.read_status() == 0
+
+
+def test_dense_u8_4m_workspace_route(ops, L):
+    """u8 dense steps take the workspace route from 2^22 cubes (their state ping-pong no longer fits the Infinity Cache): the
+    two-launch result equals the one-launch kernel's, byte for byte (states, flags, reward, one-hot)."""
+    cs, n = 3, 1 << 22
+    assert L.lib().rc_workspace_bytes(L.OP_STEP, cs, n, L.FMT_U8) == 20 * n
+    st = ops.alloc_states(n, cs, "cuda")
+    ops.fill_solved(st, n, cs)
+    ops.scramble(st, n, cs, 7, seed=11)
+    acts = torch.randint(0, 13, (n,), dtype=torch.uint8, device="cuda")              # incl. the no-op action 12
+    outs = []
+    for variant in (0, 200000):                                                        # workspace route / one-launch kernel
+        dst = torch.zeros_like(st)
+        oh = torch.full((n, 20, 24), 3, dtype=torch.uint8, device="cuda")
+        rew = torch.zeros(n, dtype=torch.float32, device="cuda")
+        done = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
+        ops.apply_moves(st, dst, acts, n, cs, rew, done, oh, L.FMT_U8, variant=variant)
+        outs.append((dst, oh, rew, done))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert int(outs[0][1].sum()) == 20 * n and L.read_status() == 0

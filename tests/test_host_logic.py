@@ -116,12 +116,13 @@ def test_abi_exports_every_declared_symbol():
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = {l.split()[-1] for l in nm.splitlines() if " T " in l}
     assert {e for e in exported if e.startswith("rc_")} == declared, exported ^ declared
-    # the workspace query needs no GPU: 20 bytes per cube in 32768-cube tiles for large 3x3x3 f32 dense steps, 0 where no
-    # workspace is used (small batches, 2x2x2, the 1- and 2-byte formats, other operations)
+    # the workspace query needs no GPU: 20 bytes per cube in 32768-cube tiles for large 3x3x3 dense steps (f32 / 16-bit from 2^17
+    # cubes, u8 from 2^22), 0 where no workspace is used (small batches, 2x2x2, the compact code, other operations)
     W = lambda *a: L.rc_workspace_bytes(*a)
     assert W(_lib.OP_STEP, 3, 1 << 20, _lib.FMT_F32) == 20 << 20 and W(_lib.OP_STEP, 3, (1 << 17) + 1, _lib.FMT_F32) == 20 * ((1 << 17) + 32768)
     assert W(_lib.OP_STEP, 3, 1 << 16, _lib.FMT_F32) == 0 and W(_lib.OP_STEP, 2, 1 << 20, _lib.FMT_F32) == 0
-    assert W(_lib.OP_STEP, 3, 1 << 20, _lib.FMT_BF16) == 0 and W(_lib.OP_STEP, 3, 1 << 20, _lib.FMT_U8) == 0
+    assert W(_lib.OP_STEP, 3, 1 << 20, _lib.FMT_BF16) == 20 << 20 and W(_lib.OP_STEP, 3, 1 << 20, _lib.FMT_F16) == 20 << 20
+    assert W(_lib.OP_STEP, 3, 1 << 20, _lib.FMT_U8) == 0 and W(_lib.OP_STEP, 3, 1 << 22, _lib.FMT_U8) == 20 << 22
     assert W(_lib.OP_STEP, 3, 1 << 20, _lib.FMT_CODE) == 0 and W(_lib.OP_EXPAND, 3, 1 << 20, _lib.FMT_F32) == 0
     # include/rubiktree.h <-> librubiktree.so (host-side trees of the lockstep search)
     from rubiks_cube_solver_amd import _tree
@@ -163,22 +164,29 @@ def test_dispatch_description_and_enodev_without_gpu():
     assert L.describe(L.OP_STEP, 2, 1 << 20, outputs=st, fmt=L.FMT_BF16).startswith("k_step_dense<Cube2,bf16,move,store,TILE=256>")
     assert L.describe(L.OP_STEP, 3, 4096, outputs=0, fmt=L.FMT_F32).startswith("k_step_dense<Cube3,f32,encode,TILE=64>")
     assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 20, fmt=L.FMT_F32, variant=300000).startswith("k_code_to_dense_wide<Cube3,f32> tiles_per_group=37 grid=111")
-    # large 3x3x3 batches: the front writer, one 3840-byte pass per workgroup (2 / 4 / 8 cubes), one front per XCD
-    assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 20, fmt=L.FMT_F32).startswith("k_code_to_dense_front<Cube3,f32,F=1> cubes_per_pass=2 xcd grid=524288")
-    assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 20, fmt=L.FMT_BF16, variant=20).startswith("k_code_to_dense_front<Cube3,bf16,F=1> cubes_per_pass=4 grid=262144")
+    # large 3x3x3 batches: the front writer, one 3840-byte pass per workgroup (2 / 4 / 8 cubes), one front per XCD; f32 gathers its code
+    # bytes per lane, the 1- and 2-byte formats fetch them once per workgroup through LDS, u8 with two fronts per XCD per workgroup
+    assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 20, fmt=L.FMT_F32).startswith("k_code_to_dense_front<Cube3,f32,F=1,gather> cubes_per_pass=2 xcd grid=524288")
+    assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 20, fmt=L.FMT_BF16).startswith("k_code_to_dense_front<Cube3,bf16,F=1,lds> cubes_per_pass=4 xcd grid=262144")
+    assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 20, fmt=L.FMT_U8).startswith("k_code_to_dense_front<Cube3,u8,F=2,lds> cubes_per_pass=8 xcd grid=65536")
+    assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 20, fmt=L.FMT_BF16, variant=20).startswith("k_code_to_dense_front<Cube3,bf16,F=1,lds> cubes_per_pass=4 grid=262144")
     assert L.describe(L.OP_CODE_TO_DENSE, 2, 1 << 20, fmt=L.FMT_F32).startswith("k_code_to_dense<Cube2,f32,TILE=256>")
+    # thresholds of the front writer: 2^15 (f32), 2^16 (16-bit), 2^18 (u8); 64-cube tiles below
+    assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 14, fmt=L.FMT_F32).startswith("k_code_to_dense<Cube3,f32,TILE=64> grid=256")
+    assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 15, fmt=L.FMT_F32).startswith("k_code_to_dense_front<Cube3,f32,F=1,gather>")
+    assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 15, fmt=L.FMT_BF16).startswith("k_code_to_dense<Cube3,bf16,TILE=64> grid=512")
+    assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 16, fmt=L.FMT_BF16).startswith("k_code_to_dense_front<Cube3,bf16,F=1,lds>")
+    assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 17, fmt=L.FMT_U8).startswith("k_code_to_dense<Cube3,u8,TILE=64>")
+    assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 18, fmt=L.FMT_U8).startswith("k_code_to_dense_front<Cube3,u8,F=2,lds>")
     # rc_apply_moves_ws with its workspace: step + code, then the front writer; without (or below 2^17 cubes) the one-launch kernel
     d = L.describe(L.OP_STEP, 3, 1 << 20, outputs=st | L.OUT_REWARD | L.OUT_WORKSPACE, fmt=L.FMT_F32)
-    assert d.startswith("k_step<Cube3,V=2,move,store,code,POL=0> grid=2048 block=64 + k_code_to_dense_front<Cube3,f32,F=1> xcd grid=524288"), d
+    assert d.startswith("k_step<Cube3,V=2,move,store,code,POL=0> grid=2048 block=64 + k_code_to_dense_front<Cube3,f32,F=1,gather> xcd grid=524288"), d
+    d = L.describe(L.OP_STEP, 3, 1 << 20, outputs=st | L.OUT_REWARD | L.OUT_WORKSPACE, fmt=L.FMT_BF16)
+    assert d.startswith("k_step<Cube3,V=2,move,store,code,POL=0> grid=2048 block=64 + k_code_to_dense_front<Cube3,bf16,F=1,lds> xcd grid=262144"), d
     assert L.describe(L.OP_STEP, 3, 1 << 16, outputs=st | L.OUT_WORKSPACE, fmt=L.FMT_F32).startswith("k_step_dense<Cube3,f32,move,store,TILE=64>")
-    assert L.describe(L.OP_STEP, 3, 1 << 20, outputs=st | L.OUT_WORKSPACE, fmt=L.FMT_BF16).startswith("k_step_dense<Cube3,bf16,move,store,TILE=64> grid=16384")
+    assert L.describe(L.OP_STEP, 3, 1 << 20, outputs=st | L.OUT_WORKSPACE, fmt=L.FMT_U8).startswith("k_step_dense<Cube3,u8,move,store,TILE=256> grid=4096")
     assert L.describe(L.OP_STEP, 2, 1 << 20, outputs=st | L.OUT_WORKSPACE, fmt=L.FMT_F32).startswith("k_step_dense<Cube2,f32")
-    assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 20, fmt=L.FMT_U8).startswith("k_code_to_dense_wide<Cube3,u8>")
-    assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 15, fmt=L.FMT_F32).startswith("k_code_to_dense<Cube3,f32,TILE=64> grid=512")
-    assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 16, fmt=L.FMT_F32).startswith("k_code_to_dense_front<Cube3,f32,F=1>")       # f32: front from 2^16
-    assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 16, fmt=L.FMT_BF16).startswith("k_code_to_dense<Cube3,bf16,TILE=64> grid=1024")
-    assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 18, fmt=L.FMT_U8).startswith("k_code_to_dense<Cube3,u8,TILE=64>")            # u8: wide from 2^19
-    assert L.describe(L.OP_STEP, 3, 1 << 18, outputs=st, fmt=L.FMT_BF16).startswith("k_step_dense<Cube3,bf16,move,store,TILE=256>")   # 16-bit: 64-cube tiles from 2^19
+    assert L.describe(L.OP_STEP, 3, 1 << 18, outputs=st, fmt=L.FMT_BF16).startswith("k_step_dense<Cube3,bf16,move,store,TILE=256>")   # no workspace: 16-bit 64-cube tiles from 2^19
     assert "code,POL=4" in L.describe(L.OP_STEP, 3, 1 << 22, outputs=st | L.OUT_REWARD | L.OUT_WORKSPACE, fmt=L.FMT_F32)      # beyond the cache: code kept
     assert L.describe(L.OP_EXPAND, 3, 1 << 20, outputs=L.OUT_STATES | L.OUT_FLAGS).startswith("k_expand_stream<Cube3> grid=512")
     assert L.describe(L.OP_EXPAND, 3, 1 << 20, outputs=L.OUT_STATES | L.OUT_FLAGS, variant=800).startswith("k_expand<Cube3,V=2> parts=1 grid=2048")

@@ -38,6 +38,7 @@ BUILDS = {                      # name -> -D switches
     "aux0_pipe4": ["-DRC_DENSE_PIPE=4", "-DRC_DENSE_AUX=0"],
     "aux2_pipe4": ["-DRC_DENSE_PIPE=4", "-DRC_DENSE_AUX=2"],
     "aux17_pipe4": ["-DRC_DENSE_PIPE=4", "-DRC_DENSE_AUX=17"],
+    "gather": ["-DRC_FRONT_LDS=0"],          # front writer: one byte gather per lane instead of wave 0's load + LDS
 }
 
 
@@ -95,7 +96,8 @@ def sizes():
                 for bi in range(2):
                     oh = torch.empty((n, 20, 24), dtype=dt, device=dev)
                     row = dict(n=n, fmt=name, buf=bi)
-                    for what, v in (("c2d_default", 0), ("c2d_tile64", 100000), ("c2d_256", 200000), ("c2d_wide", 300000), ("c2d_front", 400000)):
+                    for what, v in (("c2d_default", 0), ("c2d_tile64", 100000), ("c2d_256", 200000), ("c2d_wide", 300000), ("front_gatherF1", 400031),
+                                    ("front_ldsF1", 400041), ("front_ldsF2", 400042)):
                         t = timeit(lambda: ops.onehot_from_code(code, n, 3, oh, variant=v))
                         row[what] = round((bpc + 20) * n / (t * 1e-6) / 8e12, 3)
                     for what, v in (("fused_default(ws)", 0), ("fused_tile64", 100000), ("fused_256", 200000)):
@@ -134,7 +136,7 @@ def main():
     _lib.init(dev)
     for name in BUILDS:
         path = os.path.join(CTL, f"librubikhip_{name}.so")
-        if os.path.exists(path) and not args.quick:
+        if os.path.exists(path) and (not args.quick or name == "gather"):
             L = ctypes.CDLL(path)
             _lib._declare(L)
             assert L.rc_init(0) == 0
@@ -216,6 +218,12 @@ def main():
                                     ("fused_ws: step+code, front (rc_apply_moves_ws)", lambda: fused_ws(oh), 114)):
                 t = timeit(fn)
                 emit(what=what, lib="shipped", us=t, frac=frac(t, extra), **common)
+            if "gather" in libs:
+                for what, v in (("c2d_front_xcd", 0 if fmt != _lib.FMT_U8 else 400000), ("c2d_front_linear", 400020)):
+                    t = timeit(lambda: c2d(libs["gather"], oh, fmt, v))
+                    emit(what=what, lib="gather", us=t, frac=frac(t, 20), **common)
+                t = timeit(lambda: c2d(libs["shipped"], oh, fmt, 400000))
+                emit(what="c2d_front_xcd", lib="shipped(lds)", us=t, frac=frac(t, 20), **common)
             for lname, L in libs.items():
                 if args.pmc and lname not in ("shipped", "pipe1", "ctrl1_pipe1", "ctrl2_pipe1", "ctrl2_pipe4"):
                     continue

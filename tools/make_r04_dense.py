@@ -96,17 +96,27 @@ def main():
                         + ("; session g used cube-major 32-byte code records in the workspace (not kept: f32 0.845 against 0.89 with tiled rows)" if tag == "r04g" else
                            "; session f: workspace = tiled [SLOTS][32768] code rows (the shipped layout)"),
                 "table": table(rs, lambda r: f"{r['fmt']} | {r['what']}")}
+    rs = rows("r04m_dense_quick.jsonl")
+    if rs:
+        out["front_code_fetch_session_m"] = {
+            "what": "how the front writer gets its code bytes, same process and buffers: `gather` = one byte load per lane in every wave (build -DRC_FRONT_LDS=0 of "
+                    "that session), `shipped(lds)` / `shipped` = the first 20 (u8: 40) lanes of wave 0 load aligned dwords, LDS + one barrier hand them over; "
+                    "F = fronts per XCD per workgroup",
+            "table": table(rs, lambda r: f"{r['fmt']} | {r['what']} | {r.get('lib', '-')}", lambda r: "front" in r["what"]),
+            "reading": "f32 (2 cubes per pass, ~11 lines per wave gather): gather 0.94-0.95, LDS 0.87 -> gather.  bf16: gather 0.80-0.81, LDS 0.87 -> LDS.  u8: gather 0.54, "
+                       "LDS 0.76 with one front, 0.82-0.86 with two fronts per XCD per workgroup -> LDS, F = 2 (bf16 with F = 2 is placement dependent again: 0.94 / 0.81)"}
     out["front_writer_reading"] = ("code -> dense f32 0.89-0.92 and 16-bit 0.81-0.83 on EVERY buffer (wide: 0.73-0.92 / 0.73-0.90, bimodal); u8 0.52-0.54 (two byte gathers per "
                                    "store: keeps the wide form).  More than one front per XCD per workgroup (F = 2, 4) loses.  The two-launch route is worth it for f32 "
                                    "only (0.89 against 0.70 / 0.86); bf16 fused takes 64-cube tiles (0.80-0.82 everywhere).  Scalar loads of the code rows lost "
                                    "(session e: 0.64 bf16)")
     json.dump(out, open(os.path.join(ROOT, "profiles", "r04_dense_control.json"), "w"), indent=1)
-    rs = rows("r04h_sizes.jsonl")
+    rs = rows("r04n_sizes.jsonl")
     if rs:
         json.dump({"what": "tools/dense_control.py --sizes: every dense form of the library over batch sizes 2^15 .. 2^22 (+ two ragged sizes), two output buffers each; "
-                           "fraction of the 8 TB/s peak; c2d_* = rc_onehot_from_code, fused_* = rc_apply_moves with the dense output (fused_default(ws) = "
-                           "ops.apply_moves: rc_apply_moves_ws for f32).  The f32 workspace route's 0.52 at 2^21 / 2^22 in this run is the streamed-code defect "
-                           "fixed afterwards (RowPolicy<4>: the code is kept for the next launch)",
+                           "fraction of the 8 TB/s peak; c2d_* = rc_onehot_from_code, fused_* = rc_apply_moves with the dense output (fused_default = "
+                           "ops.apply_moves: rc_apply_moves_ws where a workspace is used; front_* = the front writer with a byte gather per lane / wave 0's load + LDS, "
+                           "1 or 2 fronts per XCD per workgroup).  Session n, final kernels; the dispatch thresholds in dense_form / dense_workspace_bytes come from here "
+                           "(an earlier sweep, session h, showed the workspace route at 0.52 from 2^21 cubes while its code was streamed past the cache: RowPolicy<4>)",
                    "rows": rs}, open(os.path.join(ROOT, "profiles", "r04_dense_sizes.json"), "w"), indent=1)
     print("wrote profiles/r04_dense_control.json", os.path.getsize(os.path.join(ROOT, "profiles", "r04_dense_control.json")), "bytes")
 

@@ -17,7 +17,7 @@ int main(void) {
     const int64_t n = 5, pitch = 256;
     uint8_t *st, *act, *done, host[54 * 256], hdone[8], hact[16];
     float *reward, hrew[8];
-    if (rc_version() < 300) return 1;
+    if (rc_version() < 400) return 1;
     /* a caller that skips rc_init gets RC_ENODEV, not a raw launch error */
     if (rc_fill_solved((uint8_t *)host, n, pitch, 3, NULL) != RC_ENODEV || strlen(rc_last_error()) == 0) return 16;
     RC(rc_init(0));
@@ -85,6 +85,38 @@ int main(void) {
     RC(rc_facade_release((const uint8_t *)raw));
     CK(hipHostUnregister(raw));
     free(raw);
+    /* the workspace route from plain C: 2^17 solved cubes, all turned by U (action 0), dense float one-hot; every cube's row 0
+     * must then carry its 1 where the one-launch kernel of rc_apply_moves puts it, and no cube is solved any more */
+    {
+        const int64_t m = (int64_t)1 << 17, mp = m;
+        const int64_t need = rc_workspace_bytes(RC_OP_STEP, 3, m, RC_FMT_F32);
+        if (need != 20 * m || rc_workspace_bytes(RC_OP_STEP, 3, 4096, RC_FMT_F32) != 0) return 21;
+        uint8_t *big, *bact, *bdone, *ws;
+        float *oh_a, *oh_b;
+        CK(hipMalloc((void **)&big, 54 * mp)); CK(hipMalloc((void **)&bact, m)); CK(hipMalloc((void **)&bdone, m));
+        CK(hipMalloc((void **)&ws, need)); CK(hipMalloc((void **)&oh_a, m * 480 * sizeof(float))); CK(hipMalloc((void **)&oh_b, m * 480 * sizeof(float)));
+        CK(hipMemset(bact, 0, m));
+        RC(rc_fill_solved(big, m, mp, 3, NULL));
+        RC(rc_apply_moves_ws(big, big, bact, m, mp, mp, 3, NULL, bdone, oh_a, RC_FMT_F32, 0, ws, need, NULL));
+        RC(rc_fill_solved(big, m, mp, 3, NULL));
+        RC(rc_apply_moves(big, big, bact, m, mp, mp, 3, NULL, bdone, oh_b, RC_FMT_F32, 0, NULL));
+        float *ha = (float *)malloc(480 * sizeof(float) * 2), *hb = ha + 480;
+        for (int64_t c = 0; c < m; c += m / 7) {                 /* a few cubes across the batch, the last pass included below */
+            CK(hipMemcpy(ha, oh_a + c * 480, 480 * sizeof(float), hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hb, oh_b + c * 480, 480 * sizeof(float), hipMemcpyDeviceToHost));
+            if (memcmp(ha, hb, 480 * sizeof(float)) != 0) return 22;
+        }
+        CK(hipMemcpy(ha, oh_a + (m - 1) * 480, 480 * sizeof(float), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hb, oh_b + (m - 1) * 480, 480 * sizeof(float), hipMemcpyDeviceToHost));
+        float ones = 0;
+        for (int i = 0; i < 480; ++i) ones += ha[i];
+        if (memcmp(ha, hb, 480 * sizeof(float)) != 0 || ones != 20.0f) return 23;
+        CK(hipMemcpy(hdone, bdone, 8, hipMemcpyDeviceToHost));
+        if (hdone[0] != 0 || hdone[7] != 0) return 24;
+        if (rc_apply_moves_ws(big, big, bact, m, mp, mp, 3, NULL, bdone, oh_a, RC_FMT_F32, 0, ws + 1, need, NULL) != RC_EINVAL) return 25;   /* misaligned */
+        free(ha);
+        CK(hipFree(big)); CK(hipFree(bact)); CK(hipFree(bdone)); CK(hipFree(ws)); CK(hipFree(oh_a)); CK(hipFree(oh_b));
+    }
     uint32_t status = 99;
     RC(rc_read_status(&status, NULL));
     if (status != 0) return 8;

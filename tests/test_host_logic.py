@@ -225,6 +225,28 @@ def test_no_cpu_fallback_without_gpu():
             assert "import oracle" not in txt and "from oracle" not in txt, f
 
 
+def test_product_code_never_injects_a_backend():
+    """`CubeEnv(_backend=...)` is the seam tests/fake_backend.py uses to run the facade's host logic on CPU; it is also the one
+    seam through which the facade could run on something other than the HIP library.  No product file (the package, bench.py,
+    __graft_entry__.py, tools/) passes it: `make_env` and every `CubeEnv(...)` call construct the real VecCubeEnv."""
+    pat = re.compile(r"\b_backend\s*=")
+    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    for d in ("rubiks-cube-solver_amd", "rubiks_cube_solver_amd", "tools"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, d)):
+            files += [os.path.join(dp, f) for f in fs if f.endswith(".py")]
+    hits = []
+    for f in files:
+        for i, line in enumerate(open(f).read().splitlines(), 1):
+            if pat.search(line):
+                hits.append((os.path.relpath(f, ROOT), i, line.strip()))
+    # the only places the name is assigned: CubeEnv.__init__'s own parameter default and its construction of the real backend
+    allowed = {"rubiks-cube-solver_amd/cube_env.py"}
+    assert {h[0] for h in hits} <= allowed, hits
+    src = open(os.path.join(ROOT, "rubiks-cube-solver_amd", "cube_env.py")).read()
+    assert "return CubeEnv(device=device, cube_size=cube_size)" in src               # make_env (env.py:3-5): no backend argument
+    assert src.count("_backend=None") == 1 and "_backend = VecCubeEnv(" in src
+
+
 def test_tile_helpers():
     from rubiks_cube_solver_amd import ops
     for n, pitch in ((10, None), (5000, 1024), (40000, None), (16384, None)):

@@ -130,6 +130,9 @@ def workspace(device, nbytes):
     """Scratch tensor for rc_apply_moves_ws on `device`'s CURRENT stream (the library allocates nothing: the caller owns it).
     One per (device, stream): launches of one stream are ordered, so reusing it between calls is safe."""
     device = torch.device(device)
+    if torch.cuda.is_current_stream_capturing():
+        # under hipGraph capture the allocation belongs to the graph's private pool and lives exactly as long as the graph: never cached
+        return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
     key = (device.index if device.index is not None else torch.cuda.current_device(), stream_ptr(device).value)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:

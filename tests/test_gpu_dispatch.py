@@ -582,3 +582,35 @@ def test_dense_u8_4m_workspace_route(ops, L):
     for a, b in zip(*outs):
         assert torch.equal(a, b)
     assert int(outs[0][1].sum()) == 20 * n and L.read_status() == 0
+
+
+def test_workspace_route_under_hipgraph_capture(ops, L):
+    """ops.apply_moves with a dense float32 output on 2^17 cubes takes the workspace route; captured into a hipGraph the workspace
+    is allocated from the graph's pool (never from the per-stream cache) and every replay reproduces the eager result."""
+    cs, n = 3, 1 << 17
+    st = ops.alloc_states(n, cs, "cuda")
+    ops.fill_solved(st, n, cs)
+    ops.scramble(st, n, cs, 11, seed=5)
+    acts = torch.randint(0, 12, (n,), dtype=torch.uint8, device="cuda")
+    dst_e, dst_g = torch.zeros_like(st), torch.zeros_like(st)
+    oh_e = torch.empty((n, 20, 24), dtype=torch.float32, device="cuda")
+    oh_g = torch.full((n, 20, 24), 3.0, dtype=torch.float32, device="cuda")
+    done = torch.empty(n, dtype=torch.uint8, device="cuda")
+    ops.apply_moves(st, dst_e, acts, n, cs, None, done, oh_e, L.FMT_F32)
+    cached = dict(ops._workspaces)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.apply_moves(st, dst_g, acts, n, cs, None, done, oh_g, L.FMT_F32)      # warm-up on the capture stream
+        with torch.cuda.graph(g, stream=side):
+            ops.apply_moves(st, dst_g, acts, n, cs, None, done, oh_g, L.FMT_F32)
+    torch.cuda.current_stream().wait_stream(side)
+    assert all(k in ops._workspaces and ops._workspaces[k] is v for k, v in cached.items())   # the capture added nothing it keeps
+    for _ in range(3):
+        oh_g.fill_(3.0)
+        dst_g.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(oh_g, oh_e) and torch.equal(dst_g, dst_e)
+    assert L.read_status() == 0

@@ -5,7 +5,7 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
-TAG=${1:-r03}
+TAG=${1:-r04}
 mkdir -p $O
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
   python -m pytest tests -m gpu -x -q > $O/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/${TAG}_pytest.log

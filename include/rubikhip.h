@@ -111,6 +111,10 @@ int64_t rc_workspace_bytes(int op, int cube_size, int64_t n_cubes, int fmt);
 int rc_apply_moves_ws(const uint8_t *in, uint8_t *out, const uint8_t *actions, int64_t n_cubes,
                       int64_t pitch_in, int64_t pitch_out, int cube_size, float *reward, uint8_t *done,
                       void *onehot, int fmt, int64_t code_pitch, void *workspace, int64_t workspace_bytes, void *stream);
+/* rc_encode with a caller-owned workspace (the same rc_workspace_bytes(RC_OP_STEP, ...) bytes): a dense one-hot of a large 3x3x3
+ * batch is then encoded into the workspace as compact codes and expanded by the front writer.  Results identical to rc_encode. */
+int rc_encode_ws(const uint8_t *st, int64_t n_cubes, int64_t pitch, int cube_size, void *onehot, int fmt, int64_t code_pitch,
+                 void *workspace, int64_t workspace_bytes, void *stream);
 /* Same with a per-call tuning override (see "Tuning override" at the end; 0 = rc_apply_moves). */
 int rc_apply_moves_ex(const uint8_t *in, uint8_t *out, const uint8_t *actions, int64_t n_cubes,
                       int64_t pitch_in, int64_t pitch_out, int cube_size, float *reward,

@@ -38,6 +38,7 @@ def _declare(L):
     L.rc_apply_moves.argtypes = [vp, vp, vp, i64, i64, i64, i32, vp, vp, vp, i32, i64, vp]
     L.rc_apply_moves_ex.argtypes = [vp, vp, vp, i64, i64, i64, i32, vp, vp, vp, i32, i64, vp, i32]
     L.rc_apply_moves_ws.argtypes = [vp, vp, vp, i64, i64, i64, i32, vp, vp, vp, i32, i64, vp, i64, vp]
+    L.rc_encode_ws.argtypes = [vp, i64, i64, i32, vp, i32, i64, vp, i64, vp]
     L.rc_workspace_bytes.argtypes = [i32, i32, i64, i32]
     L.rc_workspace_bytes.restype = i64
     L.rc_facade_step.argtypes = [vp, i64, i32, i32, vp, ctypes.c_uint32, i32, vp]
@@ -60,7 +61,7 @@ def _declare(L):
     for name in ("rc_init", "rc_get_tables", "rc_fill_solved", "rc_apply_moves", "rc_apply_moves_ex", "rc_facade_step", "rc_facade_steps", "rc_facade_expand", "rc_scramble",
                  "rc_legacy_scramble_actions", "rc_is_solved", "rc_encode", "rc_onehot_from_code", "rc_expand_children",
                  "rc_expand_children_ex", "rc_adi_generate", "rc_adi_generate_ex", "rc_adi_targets", "rc_read_status",
-                 "rc_describe_dispatch", "rc_facade_release", "rc_onehot_from_code_ex", "rc_apply_moves_ws"):
+                 "rc_describe_dispatch", "rc_facade_release", "rc_onehot_from_code_ex", "rc_apply_moves_ws", "rc_encode_ws"):
         getattr(L, name).restype = i32
 
 

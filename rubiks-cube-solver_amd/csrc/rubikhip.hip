@@ -1052,7 +1052,7 @@ int launch_step(const StepArgs &a, hipStream_t st, int pol) {
     RC_GRID(blocks);
     const dim3 g((unsigned)blocks), b(BLOCK);
     if (pol == 4) {
-        if constexpr (MOVE && STORE && CODE) hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, 4, BLOCK>), g, b, 0, st, a);
+        if constexpr (CODE) hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, 4, BLOCK>), g, b, 0, st, a);
         else return fail(RC_EINVAL, "row policy 4 belongs to the workspace route%s");
     } else if (pol == 3) hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, 3, BLOCK>), g, b, 0, st, a);
     else if (pol == 2) hipLaunchKernelGGL((k_step<T, V, MOVE, STORE, CODE, 2, BLOCK>), g, b, 0, st, a);
@@ -1425,14 +1425,14 @@ static int step_common(const uint8_t *in, uint8_t *out, const uint8_t *actions, 
         if (fmt >= RC_FMT_U8) {
             if constexpr (T::SIZE == 3) {
                 const int64_t need = dense_workspace_bytes(3, n, fmt);
-                if (move && workspace && need > 0 && workspace_bytes >= need && (variant / 100000) % 10 == 0) {
-                    // step + reward + done + compact code (into the workspace), then the front writer: the dense stream leaves as
-                    // one sweeping window instead of thousands of private 240-KiB streams (k_code_to_dense_front)
+                if (workspace && need > 0 && workspace_bytes >= need && (variant / 100000) % 10 == 0) {
+                    // step (or encode) + reward + done + compact code (into the workspace), then the front writer: the dense stream
+                    // leaves as one sweeping window instead of thousands of private 240-KiB streams (k_code_to_dense_front)
                     StepArgs a2 = a;
                     a2.code = static_cast<uint8_t *>(workspace);
                     a2.code_pitch = kWsTile;
                     a2.sh_code = 15;                                                 // log2(kWsTile)
-                    if (int rc = dispatch_step<T, true, true, true>(a2, st, variant, true)) return rc;
+                    if (int rc = move ? dispatch_step<T, true, true, true>(a2, st, variant, true) : dispatch_step<T, false, false, true>(a2, st, variant, true)) return rc;
                     return launch_code_to_dense_front<T>(a2.code, n, a2.code_pitch, a2.sh_code, onehot, fmt, st, 0);
                 }
             }
@@ -1517,6 +1517,14 @@ int rc_is_solved(const uint8_t *stp, int64_t n, int64_t pitch, int cube_size, ui
 int rc_encode(const uint8_t *stp, int64_t n, int64_t pitch, int cube_size, void *onehot, int fmt, int64_t code_pitch, void *stream) {
     if (fmt == RC_FMT_NONE) return fail(RC_EINVAL, "rc_encode: fmt must not be RC_FMT_NONE%s");
     return step_common(stp, nullptr, nullptr, n, pitch, 0, cube_size, nullptr, nullptr, onehot, fmt, code_pitch, stream, false, false, 0);
+}
+
+int rc_encode_ws(const uint8_t *stp, int64_t n, int64_t pitch, int cube_size, void *onehot, int fmt, int64_t code_pitch, void *workspace,
+                 int64_t workspace_bytes, void *stream) {
+    if (fmt == RC_FMT_NONE) return fail(RC_EINVAL, "rc_encode: fmt must not be RC_FMT_NONE%s");
+    if (workspace && !aligned16(workspace)) return fail(RC_EINVAL, "workspace must be 16-byte aligned%s");
+    if (workspace_bytes < 0) return fail(RC_EINVAL, "workspace_bytes is negative%s");
+    return step_common(stp, nullptr, nullptr, n, pitch, 0, cube_size, nullptr, nullptr, onehot, fmt, code_pitch, stream, false, false, 0, workspace, workspace_bytes);
 }
 
 int rc_onehot_from_code_ex(const uint8_t *code, int64_t n, int64_t code_pitch, int cube_size, void *onehot, int fmt, void *stream, int variant) {
@@ -1719,13 +1727,13 @@ int rc_describe_dispatch(int op, int cube_size, int64_t n, int depth, unsigned o
         if (op == RC_OP_STEP) {
             if (fmt >= RC_FMT_U8 && fmt <= RC_FMT_BF16) {
                 static const char *const names[] = {"", "", "u8", "f16", "f32", "bf16"};
-                if ((outputs & RC_OUT_WORKSPACE) && states && dense_workspace_bytes(T::SIZE, n, fmt) > 0 && (variant / 100000) % 10 == 0) {
-                    StepPlan p = plan_step<T>(n, true, outputs & RC_OUT_INPLACE, true, outputs & RC_OUT_DONE, outputs & RC_OUT_REWARD, variant);
+                if ((outputs & RC_OUT_WORKSPACE) && dense_workspace_bytes(T::SIZE, n, fmt) > 0 && (variant / 100000) % 10 == 0) {
+                    StepPlan p = plan_step<T>(n, states, states && (outputs & RC_OUT_INPLACE), true, outputs & RC_OUT_DONE, outputs & RC_OUT_REWARD, variant);
                     if (p.pol != 0) p.pol = 4;
                     const int cpp = fmt == RC_FMT_F32 ? 2 : fmt == RC_FMT_U8 ? 8 : 4;
                     const FrontShape fs = front_shape(fmt, 0);
-                    snprintf(buf, buflen, "k_step<%s,V=%d,move,store,code,POL=%d> grid=%lld block=64 + k_code_to_dense_front<%s,%s,F=%d,%s> xcd grid=%lld block=256", cube, p.v,
-                             p.pol, (long long)((n + 256 * p.v - 1) / (256 * p.v)), cube, names[fmt], fs.f, fs.lds ? "lds" : "gather",
+                    snprintf(buf, buflen, "k_step<%s,V=%d%s,code,POL=%d> grid=%lld block=64 + k_code_to_dense_front<%s,%s,F=%d,%s> xcd grid=%lld block=256", cube, p.v,
+                             states ? ",move,store" : "", p.pol, (long long)((n + 256 * p.v - 1) / (256 * p.v)), cube, names[fmt], fs.f, fs.lds ? "lds" : "gather",
                              (long long)(((n + cpp - 1) / cpp + 8 * fs.f - 1) / (8 * fs.f) * 8));
                     return RC_OK;
                 }

@@ -224,6 +224,11 @@ def encode(st, n, cube_size, onehot, fmt):
     pitch = _tiled(st, S, n, "encode")
     oh, cp = _onehot_args(onehot, fmt, n, cube_size, "encode")
     _lib.init(st.device)
+    need = lib().rc_workspace_bytes(_lib.OP_STEP, cube_size, n, fmt) if fmt >= _lib.FMT_U8 else 0
+    if need > 0:                                                 # large dense batches: codes into the workspace, then the front writer
+        ws = workspace(st.device, need)
+        check(lib().rc_encode_ws(ptr(st), n, pitch, cube_size, ptr(oh), fmt, cp, ptr(ws), ws.numel(), stream_ptr(st.device)))
+        return
     check(lib().rc_encode(ptr(st), n, pitch, cube_size, ptr(oh), fmt, cp, stream_ptr(st.device)))
 
 

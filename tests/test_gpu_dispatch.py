@@ -523,6 +523,11 @@ def test_dense_front_forms_and_workspace_route(ops, L, oracle, n):
             oh.fill_(3)
             ops.apply_moves(work, work, a_d, n, cs, None, done, oh, fmt)                  # in place, with the workspace
             assert torch.equal(work, dst) and torch.equal(ref, oh), tag
+            # encode-only with the workspace (ops.encode = rc_encode_ws): the one-hot of the MOVED states, no state written
+            enc = torch.full((n, 20, 24), 3, dtype=dt, device="cuda")
+            keep = dst.clone()
+            ops.encode(dst, n, cs, enc, fmt)
+            assert torch.equal(enc, ref) and torch.equal(dst, keep), tag
             # a workspace that is too small (or NULL) falls back to the one-launch kernel: same results
             ws = torch.empty(need - 16, dtype=torch.uint8, device="cuda")
             oh.fill_(3)

@@ -110,7 +110,7 @@ def test_abi_exports_every_declared_symbol():
     assert len(declared) >= 15
     for name in declared:
         assert hasattr(L, name), name
-    assert L.rc_version() >= 400 and len(declared) == 26 and {"rc_describe_dispatch", "rc_facade_release", "rc_apply_moves_ws", "rc_workspace_bytes"} <= declared
+    assert L.rc_version() >= 400 and len(declared) == 27 and {"rc_describe_dispatch", "rc_facade_release", "rc_apply_moves_ws", "rc_encode_ws", "rc_workspace_bytes"} <= declared
     # every rc_* the library exports is declared in the header, and nothing else leaves it
     import subprocess
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
@@ -188,6 +188,8 @@ def test_dispatch_description_and_enodev_without_gpu():
     assert L.describe(L.OP_STEP, 2, 1 << 20, outputs=st | L.OUT_WORKSPACE, fmt=L.FMT_F32).startswith("k_step_dense<Cube2,f32")
     assert L.describe(L.OP_STEP, 3, 1 << 18, outputs=st, fmt=L.FMT_BF16).startswith("k_step_dense<Cube3,bf16,move,store,TILE=256>")   # no workspace: 16-bit 64-cube tiles from 2^19
     assert "code,POL=4" in L.describe(L.OP_STEP, 3, 1 << 22, outputs=st | L.OUT_REWARD | L.OUT_WORKSPACE, fmt=L.FMT_F32)      # beyond the cache: code kept
+    d = L.describe(L.OP_STEP, 3, 1 << 20, outputs=L.OUT_WORKSPACE, fmt=L.FMT_F32)                                              # rc_encode_ws
+    assert d.startswith("k_step<Cube3,V=2,code,POL=0> grid=2048 block=64 + k_code_to_dense_front<Cube3,f32,F=1,gather> xcd"), d
     assert L.describe(L.OP_EXPAND, 3, 1 << 20, outputs=L.OUT_STATES | L.OUT_FLAGS).startswith("k_expand_stream<Cube3> grid=512")
     assert L.describe(L.OP_EXPAND, 3, 1 << 20, outputs=L.OUT_STATES | L.OUT_FLAGS, variant=800).startswith("k_expand<Cube3,V=2> parts=1 grid=2048")
     assert L.describe(L.OP_EXPAND, 3, 4096, outputs=L.OUT_STATES | L.OUT_FLAGS).startswith("k_expand<Cube3,V=1>")

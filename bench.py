@@ -257,6 +257,12 @@ def other_configs(torch, ops, _lib, dev, acts):
     rec("ADI 100k x 30 codes", "ADI 100k x 30 with compact codes instead of child stickers (parent stickers + 13 codes + flags + actions)", D(_lib.OP_ADI, CUBE, W, DEPTH, outputs=CODE | FLAGS),
         W * DEPTH, "walk-depths", 54 + 1 + 12 + 13 * 20, t, f"output tiles of {pt} walks")
     del ab
+    pt, ab = ops.adi_buffers(W, DEPTH, CUBE, dev, parents=True, family=True)
+    t = timed(lambda: ops.adi_generate(W, DEPTH, CUBE, pt, dev, seed=2024, **ab), 10, 3)
+    rec("ADI 100k x 30 family", "ADI 100k x 30 with the 51-byte FAMILY record instead of the 13 codes (parent stickers + 51 shared look-ups + flags + actions): "
+        "what adi_samples launches", D(_lib.OP_ADI, CUBE, W, DEPTH, outputs=_lib.OUT_FAMILY | FLAGS), W * DEPTH, "walk-depths", 54 + 1 + 12 + 51, t,
+        f"output tiles of {pt} walks; 118 B per (walk, depth) against 327 B with the picked codes: the launch is VALU-bound, read the time, not the fraction")
+    del ab
     torch.cuda.empty_cache()
     out = {"records": recs, "hbm_only_frac": hbm_only["roofline"]["frac"]}
     try:                                                           # config 5 (latency-bound: microseconds, not GB/s)

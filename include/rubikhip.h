@@ -228,6 +228,21 @@ int rc_adi_generate_ex(uint64_t seed, uint64_t stream_id, int64_t walk_offset, i
  *   else target_value = max_a(child_value[a] + (-1.0f)), target_policy = first arg max;
  *   error = |double(parent_value) - double(target_value)| * weight[n]   (weight = d**-T, host).
  * child_value[a * pitch + n] (float), child_solved[a * pitch + n], parent_value[n]. */
+/* The same walks with the FAMILY record instead of parent / child codes (3x3x3 and 2x2x2): a face turn carries whole cubies, so every
+ * slot code of a parent and of its A children is one of NF shared look-ups -- 51 for the 3x3x3 (31 corner + 20 edge (slot, reading
+ * order) pairs), 15 for the 2x2x2.  family[((d * tiles + tile) * NF + row) * pitch + walk] holds them (tiled like the codes, NF rows):
+ * 51 bytes per (walk, depth) instead of 13 x 20.  rc_family_layout gives NF and rows[(A + 1)][SLOTS]: the family row that IS slot p's
+ * code of child a (a = A: the parent) -- the pick of cube_env.py:212-236 / py333.py:224-227 as a table.  rc_onehot_from_family
+ * (3x3x3) expands one depth's rows ([tile][NF][pitch], n walks) to the dense one-hots of all A children and the parent in one
+ * launch: child a at onehot + a * block_stride cubes, the parent as block A (block_stride >= n). */
+int rc_adi_generate_family(uint64_t seed, uint64_t stream_id, int64_t walk_offset, int64_t n_walks,
+                           int depth, int cube_size, int64_t pitch, const uint8_t *actions_in,
+                           uint8_t *actions_out, uint8_t *parents, uint8_t *family, uint8_t *child_solved,
+                           void *stream, int variant);
+int rc_family_layout(int cube_size, uint8_t *rows, int32_t *n_rows);
+int rc_onehot_from_family(const uint8_t *family, int64_t n_cubes, int64_t pitch, int cube_size, void *onehot,
+                          int fmt, int64_t block_stride, void *stream);
+
 int rc_adi_targets(const float *child_value, const uint8_t *child_solved, const float *parent_value,
                    const double *weight, int64_t n, int64_t pitch, int cube_size,
                    float *target_value, int32_t *target_policy, double *error, void *stream);
@@ -255,6 +270,7 @@ int rc_read_status(uint32_t *status, void *stream);
 #define RC_OUT_REWARD 8u
 #define RC_OUT_INPLACE 16u
 #define RC_OUT_DONE 32u
+#define RC_OUT_FAMILY 128u     /* RC_OP_ADI: the family record instead of codes (rc_adi_generate_family) */
 #define RC_OUT_WORKSPACE 64u   /* RC_OP_STEP with a dense fmt: what rc_apply_moves_ws launches when given its workspace */
 int rc_describe_dispatch(int op, int cube_size, int64_t n, int depth, unsigned outputs, int fmt, int variant,
                          char *buf, int buflen);

@@ -54,6 +54,9 @@ def _declare(L):
     L.rc_expand_children_ex.argtypes = [vp, i64, i64, i32, vp, vp, vp, i64, vp, i32]
     L.rc_adi_generate.argtypes = [u64, u64, i64, i64, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rc_adi_generate_ex.argtypes = [u64, u64, i64, i64, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32]
+    L.rc_adi_generate_family.argtypes = [u64, u64, i64, i64, i32, i32, i64, vp, vp, vp, vp, vp, vp, i32]
+    L.rc_family_layout.argtypes = [i32, vp, vp]
+    L.rc_onehot_from_family.argtypes = [vp, i64, i64, i32, vp, i32, i64, vp]
     L.rc_adi_targets.argtypes = [vp, vp, vp, vp, i64, i64, i32, vp, vp, vp, vp]
     L.rc_read_status.argtypes = [vp, vp]
     L.rc_describe_dispatch.argtypes = [i32, i32, i64, i32, ctypes.c_uint32, i32, i32, ctypes.c_char_p, i32]
@@ -61,7 +64,8 @@ def _declare(L):
     for name in ("rc_init", "rc_get_tables", "rc_fill_solved", "rc_apply_moves", "rc_apply_moves_ex", "rc_facade_step", "rc_facade_steps", "rc_facade_expand", "rc_scramble",
                  "rc_legacy_scramble_actions", "rc_is_solved", "rc_encode", "rc_onehot_from_code", "rc_expand_children",
                  "rc_expand_children_ex", "rc_adi_generate", "rc_adi_generate_ex", "rc_adi_targets", "rc_read_status",
-                 "rc_describe_dispatch", "rc_facade_release", "rc_onehot_from_code_ex", "rc_apply_moves_ws", "rc_encode_ws"):
+                 "rc_describe_dispatch", "rc_facade_release", "rc_onehot_from_code_ex", "rc_apply_moves_ws", "rc_encode_ws", "rc_adi_generate_family", "rc_family_layout",
+                 "rc_onehot_from_family"):
         getattr(L, name).restype = i32
 
 
@@ -144,7 +148,7 @@ def read_status(device=None) -> int:
 
 
 OP_STEP, OP_EXPAND, OP_ADI, OP_CODE_TO_DENSE = 1, 2, 3, 4
-OUT_STATES, OUT_CODE, OUT_FLAGS, OUT_REWARD, OUT_INPLACE, OUT_DONE, OUT_WORKSPACE = 1, 2, 4, 8, 16, 32, 64
+OUT_STATES, OUT_CODE, OUT_FLAGS, OUT_REWARD, OUT_INPLACE, OUT_DONE, OUT_WORKSPACE, OUT_FAMILY = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 def describe(op, cube_size, n, depth=0, outputs=0, fmt=FMT_NONE, variant=0) -> str:
@@ -168,3 +172,19 @@ def get_tables(cube_size):
     out["edge_defs"] = out["edge_defs"][:NE]
     out["dims"] = (S, A, NC, NE, R, C)
     return out
+
+
+_family = {}
+
+
+def family_layout(cube_size):
+    """(NF, rows) of the FAMILY record (include/rubikhip.h rc_adi_generate_family): rows[a][p] = the family row that is slot p's code of
+    child a (a = A: the parent), uint8 numpy [A + 1, SLOTS].  Needs no GPU."""
+    if cube_size not in _family:
+        import numpy as np
+        A, SL = (12, 20) if cube_size == 3 else (6, 7)
+        rows = np.zeros((A + 1, SL), np.uint8)
+        nf = ctypes.c_int32(0)
+        check(lib().rc_family_layout(cube_size, rows.ctypes.data_as(ctypes.c_void_p), ctypes.byref(nf)))
+        _family[cube_size] = (int(nf.value), rows)
+    return _family[cube_size]

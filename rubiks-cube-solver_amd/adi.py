@@ -1,8 +1,8 @@
 """Batched ADI (autodidactic iteration) sample generation: SURVEY.md section 8 rows 14-15 and N1.
 
-Device work (librubikhip.so): the random walks and their 12-child expansion (rc_adi_generate),
-the dense one-hots the value net reads (rc_onehot_from_code) and the target assembly
-(rc_adi_targets).  The value net itself is the caller's unmodified torch module
+Device work (librubikhip.so): the random walks and their 12-child expansion (rc_adi_generate_family: the
+51-byte family record per state; 2x2x2: rc_adi_generate with codes), the dense one-hots the value net reads
+(rc_onehot_from_family / rc_onehot_from_code) and the target assembly (rc_adi_targets).  The value net itself is the caller's unmodified torch module
 (model.py:31-45), called once per depth on 13 * walks states instead of twice per sample.
 
 Reference semantics kept (gym-cube/gym_cube/envs/cube_env.py:177-252):
@@ -55,10 +55,15 @@ def adi_samples(model, cube_size, n_walks, depth, temperature, device="cuda", mo
         wc = min(chunk, n_walks - w0)
         # power-of-two pitch: the A children (and the `depth` parents) of a chunk are then ONE tiled code buffer
         # of A * tiles (depth * tiles) tiles, so a single launch turns all of them into dense one-hots
+        # 3x3x3: the generator emits the FAMILY record (51 shared look-ups per state instead of 13 x 20 picked codes) and ONE
+        # rc_onehot_from_family launch per depth expands it to the 12 child blocks + the parent block; 2x2x2 keeps the codes
+        fam = cube_size == 3
         pitch, bufs = ops.adi_buffers(wc, depth, cube_size, dev, pitch=1024 if wc <= 1024 else ops.ADI_TILE,
-                                      parent_code=True, child_code=True)
+                                      parent_code=not fam, child_code=not fam, family=fam)
         p = bufs["actions_out"].shape[1]                      # padded walk count (tiles * pitch)
         tiles = p // pitch
+        if fam:
+            prow = torch.from_numpy(_lib.family_layout(cube_size)[1][A].astype(np.int64)).to(dev)
         a_in = None
         if acts_all is not None:
             a_host = torch.zeros((depth, p), dtype=torch.uint8)
@@ -66,26 +71,30 @@ def adi_samples(model, cube_size, n_walks, depth, temperature, device="cuda", mo
             a_in = a_host.to(dev)
         ops.adi_generate(wc, depth, cube_size, pitch, dev, seed=seed, stream_id=stream_id, walk_offset=walk_offset + w0,
                          actions_in=a_in, **bufs)
-        dense = torch.empty(((A + 1) * p, R, C), dtype=ddtype, device=dev)             # A child blocks + the parents
+        dense = torch.zeros(((A + 1) * p, R, C), dtype=ddtype, device=dev)             # A child blocks + the parents (pad columns stay 0)
+        parent_code = bufs["family"].index_select(2, prow) if fam else bufs["parent_code"]   # [depth, tiles, SLOTS, pitch]
         tv = torch.empty((depth, wc), dtype=torch.float32, device=dev)
         tp = torch.empty((depth, wc), dtype=torch.int32, device=dev)
         err = torch.empty((depth, wc), dtype=torch.float64, device=dev)
         for d in range(depth):
-            ops.onehot_from_code(bufs["child_code"][d].view(A * tiles, SL, pitch), A * p, cube_size, dense[:A * p])
-            ops.onehot_from_code(bufs["parent_code"][d], wc, cube_size, dense[A * p:A * p + wc])
+            if fam:
+                ops.onehot_from_family(bufs["family"][d], wc, cube_size, dense, block_stride=p)
+            else:
+                ops.onehot_from_code(bufs["child_code"][d].view(A * tiles, SL, pitch), A * p, cube_size, dense[:A * p])
+                ops.onehot_from_code(bufs["parent_code"][d], wc, cube_size, dense[A * p:A * p + wc])
             v = model(dense[:A * p + wc].to(mdev))[0].reshape(-1).to(device=dev, dtype=torch.float32)
             child_value = v[:A * p].view(A, p)                   # exactly rc_adi_targets' [A][pitch] layout
             pv = v[A * p:].contiguous()
             w = torch.full((wc,), weights[d], dtype=torch.float64, device=dev)
             tv[d], tp[d], err[d] = ops.adi_targets(child_value.contiguous(), bufs["child_solved"][d], wc, cube_size, pv, w)
-        outs["state_code"].append(torch.stack([ops.to_aos(bufs["parent_code"][d], wc) for d in range(depth)], 1).contiguous())
+        outs["state_code"].append(torch.stack([ops.to_aos(parent_code[d], wc) for d in range(depth)], 1).contiguous())
         outs["actions"].append(bufs["actions_out"][:, :wc].t().contiguous())
         outs["target_value"].append(tv.t().contiguous())
         outs["target_policy"].append(tp.t().contiguous())
         outs["error"].append(err.t().contiguous())
         if want_state_dense:
             sd = torch.empty((depth * p, R, C), dtype=torch.uint8, device=dev)
-            ops.onehot_from_code(bufs["parent_code"].view(depth * tiles, SL, pitch), depth * p, cube_size, sd)
+            ops.onehot_from_code(parent_code.reshape(depth * tiles, SL, pitch), depth * p, cube_size, sd)
             outs["state"].append(sd.view(depth, p, R, C)[:, :wc].permute(1, 0, 2, 3).contiguous())
     _lib_status(dev)
     res = {k: torch.cat(v, 0) for k, v in outs.items()}

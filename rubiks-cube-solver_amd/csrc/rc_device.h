@@ -536,6 +536,39 @@ __device__ __forceinline__ void family_pick(const FamilyCodes<T, V> &f, Pk<V> (&
     });
 }
 
+// ---- the FAMILY record: the shared look-ups of a parent as stored rows ---------------------------------
+// Instead of the 13 x SLOTS picked codes of a parent and its children (260 bytes per 3x3x3 state), the ADI generator can emit the
+// family look-ups themselves: one byte per used (slot, reading order) pair -- NF = 51 rows for the 3x3x3 (31 corner + 20 edge), 15
+// for the 2x2x2 -- in this fixed order: corner slots q = 0 .. NC-1, reading orders id = 0 .. 5 where used, then edge slots q, id = 0, 1.
+// row[a][p] = the family row that IS slot p's code of child a (a = A: the parent itself), i.e. family_pick as a table.
+template <class T>
+struct FamilyLayout {
+    int nf, nfc;
+    uint8_t cidx[T::NC][6], eidx[T::NE > 0 ? T::NE : 1][2];
+    uint8_t row[T::A + 1][T::SLOTS];
+    constexpr FamilyLayout() : nf(0), nfc(0), cidx{}, eidx{}, row{} {
+        for (int q = 0; q < T::NC; ++q)
+            for (int id = 0; id < 6; ++id)
+                if (corner_pair_used<T>(q, id)) cidx[q][id] = (uint8_t)nf++;
+        nfc = nf;
+        for (int q = 0; q < T::NE; ++q)
+            for (int id = 0; id < 2; ++id)
+                if (edge_pair_used<T>(q, id)) eidx[q][id] = (uint8_t)nf++;
+        for (int a = 0; a <= T::A; ++a)
+            for (int p = 0; p < T::SLOTS; ++p) {
+                if (p < T::NC) {
+                    const SlotSrc src = corner_src<T>(a == T::A ? -1 : a, p);
+                    row[a][p] = cidx[src.q][corner_sigma_id(src)];
+                } else {
+                    const SlotSrc src = edge_src<T>(a == T::A ? -1 : a, p - T::NC);
+                    row[a][p] = eidx[src.q][edge_sigma_id(src)];
+                }
+            }
+    }
+};
+template <class T>
+inline constexpr FamilyLayout<T> kFamily{};
+
 // ------------------------------------------------------- dense one-hot from an LDS code tile
 // lds_code: [SLOTS][tp] bytes (tp = padded tile width), `ncubes` valid cubes, output element
 // type E in {uint8_t, uint16_t (IEEE half bits), Bf16, float}; out points at the tile's first cube.

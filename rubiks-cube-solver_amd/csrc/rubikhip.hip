@@ -334,10 +334,15 @@ __global__ void __launch_bounds__(kWideBlock) k_code_to_dense_wide(const uint8_t
 //   * F: every workgroup serves F such fronts per XCD (one pass each, all code bytes loaded before the first store), which
 //     multiplies the bytes in flight per workgroup lifetime without lengthening any front's private stream.
 // (Wave-uniform scalar loads of the rows + a select chain were tried and lost: 0.64 against 0.81, bf16.)
-template <class T, class E, int F, bool LDS>
+// FAM: `code` holds FAMILY rows ([tile][NF][pitch], rc_device.h FamilyLayout) and the launch writes A + 1 blocks -- child a's one-hots
+// at dense + a * block_stride cubes, the parent's as block A: global pass = block * passes_per_block + pass; slot r of block a is family
+// row kFamily.row[a][r] (the per-child pick, from a 260-byte table in constant memory).
+__constant__ FamilyLayout<Cube3> c_family3{};
+template <class T, class E, int F, bool LDS, bool FAM = false>
 __global__ void __launch_bounds__(256) k_code_to_dense_front(const uint8_t *__restrict__ code, int64_t n, int64_t code_pitch, int shift, E *__restrict__ dense,
-                                                             int64_t per_xcd, int64_t per_front) {
+                                                             int64_t per_xcd, int64_t per_front, int64_t block_stride = 0, int64_t ppb = 0) {
     static_assert(T::SIZE == 3);
+    constexpr int ROWS = FAM ? kFamily<T>.nf : T::SLOTS;                         // rows of one tile of the input
     constexpr int EPT = 16 / (int)sizeof(E), CPC = 480 / EPT, CPP = 240 / CPC;   // elements per chunk, chunks per cube, cubes per pass
     constexpr int WORDS = CPP > 4 ? 2 : 1;                                       // dwords of one code row that hold a pass's cubes
     // LDS: the pass's code bytes are SLOTS x WORDS aligned dwords fetched by the first lanes of wave 0 (one load instruction, 20
@@ -353,31 +358,42 @@ __global__ void __launch_bounds__(256) k_code_to_dense_front(const uint8_t *__re
     const int ra = (k * EPT) / T::C, rb = sizeof(E) >= 2 ? ra : (k * 16 + 12) / T::C;
     uint32_t ca[F], cb[F];
     bool live[F];
+    // FAM: which block (child / parent) a global pass belongs to, its pass inside the block, and the input row of slot r there
+    int blk[F];
+    int64_t lpass[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        const int64_t gp = pass0 + f * per_front;
+        blk[f] = FAM ? (int)(gp / ppb) : 0;
+        lpass[f] = FAM ? gp - (int64_t)blk[f] * ppb : gp;
+        if (FAM && blk[f] > T::A) { blk[f] = T::A; lpass[f] = ppb; }               // beyond the last block: lpass * CPP >= n, nothing live
+    }
+    auto in_row = [&](int f, int r) { return FAM ? (int)c_family3.row[blk[f]][r] : r; };
     if constexpr (LDS) {
 #pragma unroll
         for (int f = 0; f < F; ++f) {
-            const int64_t cube0 = (pass0 + f * per_front) * CPP, a0 = cube0 & ~(int64_t)3;
+            const int64_t cube0 = lpass[f] * CPP, a0 = cube0 & ~(int64_t)3;
             if (tid < T::SLOTS * WORDS && cube0 < n && (f == 0 || per_front > 0)) {
                 const int r = tid / WORDS, w = tid - r * WORDS;
-                rows[f][tid] = *reinterpret_cast<const uint32_t *>(code + tile_off(a0 + 4 * w, code_pitch, shift, T::SLOTS) + (int64_t)r * code_pitch);
+                rows[f][tid] = *reinterpret_cast<const uint32_t *>(code + tile_off(a0 + 4 * w, code_pitch, shift, ROWS) + (int64_t)in_row(f, r) * code_pitch);
             }
         }
         __syncthreads();
     }
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-        const int64_t pass = pass0 + f * per_front, cube = pass * CPP + sub;
+        const int64_t cube = lpass[f] * CPP + sub;
         live[f] = tid < 240 && cube < n && (f == 0 || per_front > 0);
         ca[f] = cb[f] = 0xff;
         if (live[f]) {
             if constexpr (LDS) {
-                const int byte = (int)((pass * CPP) & 3) + sub;                  // the cube's byte inside the row's dword(s)
+                const int byte = (int)((lpass[f] * CPP) & 3) + sub;              // the cube's byte inside the row's dword(s)
                 ca[f] = (rows[f][ra * WORDS + (byte >> 2)] >> (8 * (byte & 3))) & 0xffu;
                 if constexpr (sizeof(E) == 1) cb[f] = (rows[f][rb * WORDS + (byte >> 2)] >> (8 * (byte & 3))) & 0xffu;
             } else {
-                const uint8_t *src = code + tile_off(cube, code_pitch, shift, T::SLOTS);   // row 0 of this cube's code column
-                ca[f] = src[(int64_t)ra * code_pitch];
-                if constexpr (sizeof(E) == 1) cb[f] = src[(int64_t)rb * code_pitch];
+                const uint8_t *src = code + tile_off(cube, code_pitch, shift, ROWS);       // row 0 of this cube's column
+                ca[f] = src[(int64_t)in_row(f, ra) * code_pitch];
+                if constexpr (sizeof(E) == 1) cb[f] = src[(int64_t)in_row(f, rb) * code_pitch];
             }
         }
     }
@@ -396,7 +412,7 @@ __global__ void __launch_bounds__(256) k_code_to_dense_front(const uint8_t *__re
             }
         }
         // the pass is 3840 contiguous bytes: thread t owns bytes 16 t ..
-        bst<4, RC_DENSE_AUX>(make_srd(dense + (pass0 + f * per_front) * (CPP * 480)), (uint32_t)tid * 16u, 0, u);
+        bst<4, RC_DENSE_AUX>(make_srd(dense + ((int64_t)blk[f] * block_stride + lpass[f] * CPP) * 480), (uint32_t)tid * 16u, 0, u);
     }
 }
 
@@ -537,6 +553,7 @@ struct AdiArgs {
     int depth, parts, shift;
     const uint8_t *actions_in;
     uint8_t *actions_out, *parents, *parent_code, *children, *child_code, *child_solved;
+    uint8_t *family;                              // [depth][tile][NF][pitch]: the shared look-ups themselves (rc_device.h FamilyLayout)
     int segs;                                     // depth segments per walk group (1..kMaxSegs)
     uint16_t seg_lo[kMaxSegs + 1];                // segment s emits depths [seg_lo[s], seg_lo[s + 1])
 };
@@ -630,6 +647,26 @@ __global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
                 for (int i = 0; i < T::S; ++i) bst<V, RC_OUT_AUX>(r, lo, i * rs, s[i]);
             }
             if constexpr (CODE) {
+                if (a.family) {
+                    // the FAMILY record: every used (slot, reading order) look-up as a row of its own -- 51 bytes per state instead of the
+                    // 13 x 20 picked codes; rc_onehot_from_family does the per-child pick when it expands to dense
+                    constexpr int NF = kFamily<T>.nf;
+                    const __amdgpu_buffer_rsrc_t r = make_srd(a.family + (int64_t)d * NF * wp + tile_off(g0, a.pitch, a.shift, NF));
+                    sfor<T::NC>([&](auto qc) {
+                        constexpr int q = decltype(qc)::value;
+                        sfor<6>([&](auto ic) {
+                            constexpr int id = decltype(ic)::value;
+                            if constexpr (corner_pair_used<T>(q, id)) bst<V, RC_OUT_AUX>(r, lo, (uint32_t)kFamily<T>.cidx[q][id] * rs, fam.c[q][id]);
+                        });
+                    });
+                    sfor<T::NE>([&](auto qc) {
+                        constexpr int q = decltype(qc)::value;
+                        sfor<2>([&](auto ic) {
+                            constexpr int id = decltype(ic)::value;
+                            if constexpr (edge_pair_used<T>(q, id)) bst<V, RC_OUT_AUX>(r, lo, (uint32_t)kFamily<T>.eidx[q][id] * rs, fam.e[q][id]);
+                        });
+                    });
+                }
                 if (a.parent_code) {
                     Pk<V> pc[T::SLOTS];
                     family_pick<T, V, -1>(fam, pc);
@@ -1188,6 +1225,26 @@ int launch_front_shape(const uint8_t *code, int64_t n, int64_t code_pitch, int s
     if (s.f == 2) return launch_front_e<T, E, 2, false>(code, n, code_pitch, sh, onehot, st, s.linear);
     return launch_front_e<T, E, 1, false>(code, n, code_pitch, sh, onehot, st, s.linear);
 }
+// family rows -> the dense one-hots of all A children and the parent (block a at onehot + a * block_stride cubes): the front writer
+// over (A + 1) * ceil(n / cubes per pass) passes, same shapes per format as the code -> dense launch
+template <class T, class E, int F, bool LDS>
+int launch_family_e(const uint8_t *fam, int64_t n, int64_t pitch, int sh, E *onehot, int64_t block_stride, hipStream_t st) {
+    constexpr int cpp = 240 / (480 / (16 / (int)sizeof(E)));
+    const int64_t ppb = (n + cpp - 1) / cpp, passes = ppb * (T::A + 1);
+    const int64_t per_front = (passes + 8 * F - 1) / (8 * F), per_xcd = per_front * F, blocks = per_front * 8;
+    RC_GRID(blocks);
+    hipLaunchKernelGGL((k_code_to_dense_front<T, E, F, LDS, true>), dim3((unsigned)blocks), dim3(256), 0, st, fam, n, pitch, sh, onehot, per_xcd, per_front, block_stride, ppb);
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+template <class T>
+int launch_family_to_dense(const uint8_t *fam, int64_t n, int64_t pitch, int sh, void *onehot, int fmt, int64_t block_stride, hipStream_t st) {
+    if (fmt == RC_FMT_U8) return launch_family_e<T, uint8_t, 2, true>(fam, n, pitch, sh, static_cast<uint8_t *>(onehot), block_stride, st);
+    if (fmt == RC_FMT_F16) return launch_family_e<T, uint16_t, 1, true>(fam, n, pitch, sh, static_cast<uint16_t *>(onehot), block_stride, st);
+    if (fmt == RC_FMT_BF16) return launch_family_e<T, Bf16, 1, true>(fam, n, pitch, sh, static_cast<Bf16 *>(onehot), block_stride, st);
+    return launch_family_e<T, float, 1, false>(fam, n, pitch, sh, static_cast<float *>(onehot), block_stride, st);
+}
+
 template <class T>
 int launch_code_to_dense_front(const uint8_t *code, int64_t n, int64_t code_pitch, int sh, void *onehot, int fmt, hipStream_t st, int variant) {
     if constexpr (T::SIZE == 3) {
@@ -1331,7 +1388,7 @@ int launch_adi(AdiArgs a, hipStream_t st) {
     const int64_t groups = (a.n_walks + kWave * 4 * V - 1) / (kWave * 4 * V);
     RC_GRID(groups * a.parts * a.segs);
     const dim3 g((unsigned)(groups * a.parts * a.segs)), b(kWave);
-    if (a.parent_code || a.child_code) hipLaunchKernelGGL((k_adi<T, V, true>), g, b, 0, st, a);
+    if (a.parent_code || a.child_code || a.family) hipLaunchKernelGGL((k_adi<T, V, true>), g, b, 0, st, a);
     else hipLaunchKernelGGL((k_adi<T, V, false>), g, b, 0, st, a);
     RC_HIP(hipGetLastError());
     return RC_OK;
@@ -1573,10 +1630,11 @@ int rc_expand_children(const uint8_t *in, int64_t n, int64_t pitch_in, int cube_
     return rc_expand_children_ex(in, n, pitch_in, cube_size, children, child_solved, child_code, pitch_out, stream, 0);
 }
 
-int rc_adi_generate_ex(uint64_t seed, uint64_t stream_id, int64_t walk_offset, int64_t n_walks, int depth, int cube_size, int64_t pitch,
-                       const uint8_t *actions_in, uint8_t *actions_out, uint8_t *parents, uint8_t *parent_code, uint8_t *children,
-                       uint8_t *child_code, uint8_t *child_solved, void *stream, int variant) {
+static int adi_common(uint64_t seed, uint64_t stream_id, int64_t walk_offset, int64_t n_walks, int depth, int cube_size, int64_t pitch,
+                      const uint8_t *actions_in, uint8_t *actions_out, uint8_t *parents, uint8_t *parent_code, uint8_t *children,
+                      uint8_t *child_code, uint8_t *child_solved, uint8_t *family, void *stream, int variant) {
     RC_NEED_INIT();
+    if (family && !aligned16(family)) return fail(RC_EINVAL, "rc_adi_generate: buffers must be 16-byte aligned%s");
     const int sh = tile_shift(pitch, n_walks);
     if (n_walks < 0 || depth < 0 || sh < 0) return fail(RC_EINVAL, "rc_adi_generate: bad sizes / pitch%s");
     const void *ptrs[] = {actions_in, actions_out, parents, parent_code, children, child_code, child_solved};
@@ -1586,13 +1644,14 @@ int rc_adi_generate_ex(uint64_t seed, uint64_t stream_id, int64_t walk_offset, i
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
         const bool any_child = children || child_code || child_solved;
-        Geometry geo = pick_geometry_adi(n_walks, T::A, variant, children != nullptr, n_walks * depth * T::S * T::A, parent_code || child_code);
+        Geometry geo = pick_geometry_adi(n_walks, T::A, variant, children != nullptr, n_walks * depth * T::S * T::A, parent_code || child_code || family);
         if (!any_child && (variant / 1000) % 100 == 0) geo.parts = 1;
+        if (family && (variant / 1000000) % 100 == 0 && geo.segs > 1) geo.segs += 1;   // fewer stores per emitted depth: one more segment (64 against 71 us at 100k x 30)
         AdiArgs a{seed, stream_id, walk_offset, n_walks, pitch, n_walks <= pitch ? 1 : (n_walks + pitch - 1) / pitch, depth,
-                  geo.parts, sh, actions_in, actions_out, parents, parent_code, children, child_code, child_solved, 1, {}};
+                  geo.parts, sh, actions_in, actions_out, parents, parent_code, children, child_code, child_solved, family, 1, {}};
         if (depth > 0xffff) return fail(RC_EINVAL, "rc_adi_generate: depth must be below 65536%s");
         const int fsegs = (variant / 1000000) % 100;
-        const bool codes = parent_code || child_code;
+        const bool codes = parent_code || child_code || family;
         // a replayed depth is RNG + move; an emitted one adds the flags, the code look-ups and the stores
         fill_segments(a, fsegs ? fsegs : geo.segs, codes ? kReplayCostCodes : kReplayCostStickers);
         hipStream_t st = S(stream);
@@ -1600,11 +1659,46 @@ int rc_adi_generate_ex(uint64_t seed, uint64_t stream_id, int64_t walk_offset, i
     });
 }
 
+int rc_adi_generate_ex(uint64_t seed, uint64_t stream_id, int64_t walk_offset, int64_t n_walks, int depth, int cube_size, int64_t pitch,
+                       const uint8_t *actions_in, uint8_t *actions_out, uint8_t *parents, uint8_t *parent_code, uint8_t *children,
+                       uint8_t *child_code, uint8_t *child_solved, void *stream, int variant) {
+    return adi_common(seed, stream_id, walk_offset, n_walks, depth, cube_size, pitch, actions_in, actions_out, parents, parent_code, children, child_code,
+                      child_solved, nullptr, stream, variant);
+}
+
 int rc_adi_generate(uint64_t seed, uint64_t stream_id, int64_t walk_offset, int64_t n_walks, int depth, int cube_size, int64_t pitch,
                     const uint8_t *actions_in, uint8_t *actions_out, uint8_t *parents, uint8_t *parent_code, uint8_t *children,
                     uint8_t *child_code, uint8_t *child_solved, void *stream) {
     return rc_adi_generate_ex(seed, stream_id, walk_offset, n_walks, depth, cube_size, pitch, actions_in, actions_out, parents, parent_code,
                               children, child_code, child_solved, stream, 0);
+}
+
+int rc_adi_generate_family(uint64_t seed, uint64_t stream_id, int64_t walk_offset, int64_t n_walks, int depth, int cube_size, int64_t pitch,
+                           const uint8_t *actions_in, uint8_t *actions_out, uint8_t *parents, uint8_t *family, uint8_t *child_solved, void *stream,
+                           int variant) {
+    if (!family) return fail(RC_EINVAL, "rc_adi_generate_family: family is NULL%s");
+    return adi_common(seed, stream_id, walk_offset, n_walks, depth, cube_size, pitch, actions_in, actions_out, parents, nullptr, nullptr, nullptr, child_solved,
+                      family, stream, variant);
+}
+
+int rc_family_layout(int cube_size, uint8_t *rows, int32_t *n_rows) {
+    return by_size(cube_size, [&](auto t) {
+        using T = decltype(t);
+        if (rows) memcpy(rows, kFamily<T>.row, sizeof kFamily<T>.row);
+        if (n_rows) *n_rows = kFamily<T>.nf;
+        return RC_OK;
+    });
+}
+
+int rc_onehot_from_family(const uint8_t *family, int64_t n, int64_t pitch, int cube_size, void *onehot, int fmt, int64_t block_stride, void *stream) {
+    RC_NEED_INIT();
+    if (cube_size != 3) return fail(RC_EINVAL, "rc_onehot_from_family: 3x3x3 only%s");
+    const int sh = tile_shift(pitch, n, kFamily<Cube3>.nf);
+    if (!family || !aligned16(family) || n < 0 || sh < 0) return fail(RC_EINVAL, "bad family buffer / pitch%s");
+    if (fmt < RC_FMT_U8 || fmt > RC_FMT_BF16 || !onehot || !aligned16(onehot)) return fail(RC_EINVAL, "rc_onehot_from_family: dense fmt and aligned buffer required%s");
+    if (block_stride < n) return fail(RC_EINVAL, "rc_onehot_from_family: block_stride must be >= n_cubes%s");
+    if (n == 0) return RC_OK;
+    return launch_family_to_dense<Cube3>(family, n, pitch, sh, onehot, fmt, block_stride, S(stream));
 }
 
 int rc_adi_targets(const float *child_value, const uint8_t *child_solved, const float *parent_value, const double *weight, int64_t n,
@@ -1778,14 +1872,16 @@ int rc_describe_dispatch(int op, int cube_size, int64_t n, int depth, unsigned o
         }
         if (op == RC_OP_ADI) {
             if (depth <= 0) return fail(RC_EINVAL, "rc_describe_dispatch: depth must be positive%s");
-            Geometry geo = pick_geometry_adi(n, T::A, variant, states, n * depth * T::S * T::A, code);
+            const bool family = outputs & RC_OUT_FAMILY;
+            Geometry geo = pick_geometry_adi(n, T::A, variant, states, n * depth * T::S * T::A, code || family);
+            if (family && (variant / 1000000) % 100 == 0 && geo.segs > 1) geo.segs += 1;
             const bool any_child = states || code || (outputs & RC_OUT_FLAGS);
             if (!any_child && (variant / 1000) % 100 == 0) geo.parts = 1;
             AdiArgs a{};
             a.depth = depth;
             const int fsegs = (variant / 1000000) % 100;
-            fill_segments(a, fsegs ? fsegs : geo.segs, code ? kReplayCostCodes : kReplayCostStickers);
-            snprintf(buf, buflen, "k_adi<%s,V=%d%s> parts=%d segs=%d grid=%lld block=64", cube, geo.v, code ? ",code" : "", geo.parts, a.segs,
+            fill_segments(a, fsegs ? fsegs : geo.segs, code || family ? kReplayCostCodes : kReplayCostStickers);
+            snprintf(buf, buflen, "k_adi<%s,V=%d%s> parts=%d segs=%d grid=%lld block=64", cube, geo.v, family ? ",code,family" : code ? ",code" : "", geo.parts, a.segs,
                      (long long)((n + 256 * geo.v - 1) / (256 * geo.v) * geo.parts * a.segs));
             return RC_OK;
         }

@@ -241,6 +241,20 @@ def onehot_from_code(code, n, cube_size, onehot, variant=0):
     check(lib().rc_onehot_from_code_ex(ptr(code), n, cp, cube_size, ptr(onehot), fmt, stream_ptr(code.device), variant))
 
 
+def onehot_from_family(family, n, cube_size, onehot, block_stride):
+    """One depth's FAMILY rows ([tiles, NF, pitch] or [NF, pitch], n walks) -> the dense one-hots of all A children and the parent in ONE
+    launch: child a fills onehot[a * block_stride : a * block_stride + n], the parent onehot[A * block_stride : ...] (3x3x3)."""
+    _, A, _ = _size(cube_size)
+    nf = _lib.family_layout(cube_size)[0]
+    pitch = _tiled(family, nf, n, "onehot_from_family")
+    fmt = _lib.fmt_of(onehot.dtype)
+    R, C = STATE_DIM[cube_size]
+    if not onehot.is_cuda or not onehot.is_contiguous() or onehot.dim() != 3 or tuple(onehot.shape[1:]) != (R, C) or onehot.shape[0] < A * block_stride + n:
+        raise RubikHipError(f"onehot_from_family: need a contiguous HIP tensor [>= {A} * block_stride + n, {R}, {C}]")
+    _lib.init(family.device)
+    check(lib().rc_onehot_from_family(ptr(family), n, pitch, cube_size, ptr(onehot), fmt, block_stride, stream_ptr(family.device)))
+
+
 def _tiles_of(n, pitch):
     if pitch % 16:
         raise RubikHipError(f"pitch {pitch} must be a multiple of 16")
@@ -309,8 +323,9 @@ ADI_TILE = 16384   # walks per output tile: measured best for the ADI kernel's o
 
 
 def adi_buffers(n_walks, depth, cube_size, device, pitch=None, actions=True, parents=False, parent_code=False,
-                children=False, child_code=False, child_solved=True):
-    """Allocate rc_adi_generate outputs with one tiling (see include/rubikhip.h).  Returns (pitch, dict)."""
+                children=False, child_code=False, child_solved=True, family=False):
+    """Allocate rc_adi_generate outputs with one tiling (see include/rubikhip.h).  Returns (pitch, dict).
+    family: the [depth, tiles, NF, pitch] FAMILY record of rc_adi_generate_family (instead of parent_code / child_code)."""
     S, A, SL = _size(cube_size)
     if pitch is None:
         pitch = _lib.pitch_for(n_walks) if n_walks <= ADI_TILE else ADI_TILE
@@ -329,12 +344,15 @@ def adi_buffers(n_walks, depth, cube_size, device, pitch=None, actions=True, par
         out["child_code"] = e(depth, A, tiles, SL, pitch)
     if child_solved:
         out["child_solved"] = e(depth, A, tiles * pitch)
+    if family:
+        out["family"] = e(depth, tiles, _lib.family_layout(cube_size)[0], pitch)
     return pitch, out
 
 
 def adi_generate(n_walks, depth, cube_size, pitch, device, seed=0, stream_id=0, walk_offset=0, actions_in=None,
-                 actions_out=None, parents=None, parent_code=None, children=None, child_code=None, child_solved=None, variant=0):
-    """ADI walks + expansion (cube_env.py:177-194,212-236); layouts in include/rubikhip.h / adi_buffers."""
+                 actions_out=None, parents=None, parent_code=None, children=None, child_code=None, child_solved=None, family=None, variant=0):
+    """ADI walks + expansion (cube_env.py:177-194,212-236); layouts in include/rubikhip.h / adi_buffers.
+    family: emit the FAMILY record (rc_adi_generate_family) -- then no parent_code / child_code / children."""
     S, A, SL = _size(cube_size)
     tiles = _tiles_of(n_walks, pitch)
     _out(actions_in, (depth,), tiles, 0, pitch, "actions_in")
@@ -346,6 +364,13 @@ def adi_generate(n_walks, depth, cube_size, pitch, device, seed=0, stream_id=0, 
     _out(child_solved, (depth, A), tiles, 0, pitch, "child_solved")
     dev = torch.device(device)
     _lib.init(dev)
+    if family is not None:
+        if parent_code is not None or child_code is not None or children is not None:
+            raise RubikHipError("adi_generate: the family record replaces parent_code / child_code / children")
+        _out(family, (depth,), tiles, _lib.family_layout(cube_size)[0], pitch, "family")
+        check(lib().rc_adi_generate_family(seed, stream_id, walk_offset, n_walks, depth, cube_size, pitch, ptr(actions_in), ptr(actions_out),
+                                           ptr(parents), ptr(family), ptr(child_solved), stream_ptr(dev), variant))
+        return
     check(lib().rc_adi_generate_ex(seed, stream_id, walk_offset, n_walks, depth, cube_size, pitch, ptr(actions_in),
                                    ptr(actions_out), ptr(parents), ptr(parent_code), ptr(children), ptr(child_code),
                                    ptr(child_solved), stream_ptr(dev), variant))

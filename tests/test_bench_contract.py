@@ -82,10 +82,12 @@ def test_bench_json_line():
     pc = {x["name"]: x for x in r["per_config"]}
     for name in ("cfg2 1M step+reward", "4M step in place", "4M step+reward", "4M step+reward+code", "16M step (HBM only)",
                  "1M step+dense f32", "1M step+dense bf16", "1M code->dense f32", "1M code->dense bf16", "1M expansion",
-                 "cfg3 ADI 100k x 30", "ADI 100k x 30 codes"):
+                 "cfg3 ADI 100k x 30", "ADI 100k x 30 codes", "ADI 100k x 30 family"):
         x = pc[name]
         assert x["kernel"].startswith("k_") and abs(x["frac"] - x["bytes"] / (x["launch_us"] * 1e-6) / 8e12) < 2e-3, name
     assert len(r["per_config"]) == len(recs)
+    # the family record halves the code-emitting ADI launch (118 B per (walk, depth) instead of 327 B; round-3 review: <= 110 us)
+    assert pc["ADI 100k x 30 family"]["launch_us"] < 110 and pc["ADI 100k x 30 family"]["launch_us"] < 0.7 * pc["ADI 100k x 30 codes"]["launch_us"]
 
 
 @pytest.mark.gpu

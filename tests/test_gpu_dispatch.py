@@ -280,6 +280,62 @@ def test_adi_codes_default_dispatch_100k(ops, L, oracle):
     assert (untile(ops, bufs["parent_code"], W, 1).transpose(1, 0, 2) == exp["parent_code"]).all()
     assert (untile(ops, bufs["child_code"], W, 2).transpose(2, 0, 1, 3) == exp["child_code"]).all()
     assert (bufs["child_solved"][..., :W].cpu().numpy().transpose(2, 0, 1) == exp["child_solved"]).all()
+    # the same walks as FAMILY records (51 shared look-ups per state instead of 13 x 20 picked codes): every slot code of the parent
+    # and of every child is the family row the layout table names, and one rc_onehot_from_family launch per depth gives the dense
+    # one-hots of all 12 children and the parent
+    nf, rows = L.family_layout(cs)
+    assert nf == 51 and rows.shape == (13, 20)
+    pt2, fb = ops.adi_buffers(W, D, cs, "cuda", parents=True, family=True)
+    ops.adi_generate(W, D, cs, pt2, "cuda", seed=5, stream_id=1, **fb)
+    assert (fb["actions_out"][:, :W].cpu().numpy().T == exp["actions"]).all()
+    assert (untile(ops, fb["parents"], W, 1).transpose(1, 0, 2) == exp["parents"]).all()
+    assert (fb["child_solved"][..., :W].cpu().numpy().transpose(2, 0, 1) == exp["child_solved"]).all()
+    fam = untile(ops, fb["family"], W, 1).transpose(1, 0, 2)                       # [W, D, NF]
+    assert (fam[:, :, rows[12]] == exp["parent_code"]).all()
+    for a in range(12):
+        assert (fam[:, :, rows[a]] == exp["child_code"][:, :, a]).all(), a
+    p = fb["actions_out"].shape[1]
+    for dt in (torch.float32, torch.bfloat16, torch.uint8):
+        dense = torch.full((13 * p, 20, 24), 3, dtype=dt, device="cuda")
+        for d in (0, D - 1):
+            ops.onehot_from_family(fb["family"][d], W, cs, dense, block_stride=p)
+            got = dense.view(13, p, 20, 24)[:, :W].float().argmax(-1).to(torch.uint8).cpu().numpy()   # [13, W, 20]
+            assert (got[12] == exp["parent_code"][:, d]).all() and (got[:12].transpose(1, 0, 2) == exp["child_code"][:, d]).all(), (dt, d)
+            assert float(dense.view(13, p, 20, 24)[:, :W].float().sum()) == 13.0 * 20 * W
+            assert float(dense.view(13, p, 20, 24)[:, W:].float().min()) == 3.0 if p > W else True       # pad cubes untouched
+    assert "k_adi<Cube3,V=2,code,family> parts=1 segs=4" in L.describe(L.OP_ADI, cs, W, 30, outputs=L.OUT_FAMILY | L.OUT_FLAGS)
+    assert L.read_status() == 0
+
+
+@pytest.mark.parametrize("cs", [3, 2])
+@pytest.mark.parametrize("n,pitch,variant", [(1, None, 0), (700, None, 0), (5000, 512, 0), (5000, 1024, 2001001), (40000, None, 1)])
+def test_adi_family_records_small_and_tiled(ops, L, oracle, cs, n, pitch, variant):
+    """FAMILY records on small, ragged and tiled batches, both cube sizes, forced pack widths / depth segments: the rows the layout
+    table names equal the oracle's parent and child codes (cube_env.py:212-236, py333.py:224-227), the other outputs are unchanged;
+    3x3x3: the dense expansion of every block equals the oracle's codes."""
+    D, A, SL = 5, A_OF[cs], 20 if cs == 3 else 7
+    nf, rows = L.family_layout(cs)
+    assert nf == (51 if cs == 3 else 15) and rows.shape == (A + 1, SL) and int(rows.max()) == nf - 1
+    pt, fb = ops.adi_buffers(n, D, cs, "cuda", pitch=pitch, parents=True, family=True)
+    ops.adi_generate(n, D, cs, pt, "cuda", seed=9, stream_id=2, variant=variant, **fb)
+    exp = oracle.adi(cs, n, D, seed=9, stream=2, want_children=False)
+    assert (fb["actions_out"][:, :n].cpu().numpy().T == exp["actions"]).all()
+    assert (untile(ops, fb["parents"], n, 1).transpose(1, 0, 2) == exp["parents"]).all()
+    assert (fb["child_solved"][..., :n].cpu().numpy().transpose(2, 0, 1) == exp["child_solved"]).all()
+    fam = untile(ops, fb["family"], n, 1).transpose(1, 0, 2)
+    assert (fam[:, :, rows[A]] == exp["parent_code"]).all()
+    for a in range(A):
+        assert (fam[:, :, rows[a]] == exp["child_code"][:, :, a]).all(), a
+    if cs == 3:
+        p = fb["actions_out"].shape[1]
+        dense = torch.full((13 * p + 3, 20, 24), 3, dtype=torch.float16, device="cuda")
+        ops.onehot_from_family(fb["family"][2], n, cs, dense, block_stride=p)
+        got = dense[:13 * p].view(13, p, 20, 24)[:, :n].float().argmax(-1).to(torch.uint8).cpu().numpy()
+        assert (got[12] == exp["parent_code"][:, 2]).all() and (got[:12].transpose(1, 0, 2) == exp["child_code"][:, 2]).all()
+        assert float(dense[13 * p:].float().min()) == 3.0
+    else:
+        with pytest.raises(L.RubikHipError):
+            ops.onehot_from_family(fb["family"][0], n, cs, torch.empty((7 * n + n, 7, 21), dtype=torch.float32, device="cuda"), block_stride=n)
     assert L.read_status() == 0
 
 

@@ -110,7 +110,8 @@ def test_abi_exports_every_declared_symbol():
     assert len(declared) >= 15
     for name in declared:
         assert hasattr(L, name), name
-    assert L.rc_version() >= 400 and len(declared) == 27 and {"rc_describe_dispatch", "rc_facade_release", "rc_apply_moves_ws", "rc_encode_ws", "rc_workspace_bytes"} <= declared
+    assert L.rc_version() >= 400 and len(declared) == 30 and {"rc_describe_dispatch", "rc_facade_release", "rc_apply_moves_ws", "rc_encode_ws", "rc_workspace_bytes",
+                                                              "rc_adi_generate_family", "rc_family_layout", "rc_onehot_from_family"} <= declared
     # every rc_* the library exports is declared in the header, and nothing else leaves it
     import subprocess
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
@@ -225,6 +226,26 @@ def test_no_cpu_fallback_without_gpu():
         if f.endswith(".py"):
             txt = open(os.path.join(ROOT, "rubiks-cube-solver_amd", f)).read()
             assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_family_layout_table():
+    """The FAMILY record's layout (rc_family_layout, no GPU needed): 51 | 15 shared look-ups; the parent's 20 | 7 slot codes are
+    distinct rows; every row is some (child, slot)'s code; a child's slot reads the row of the parent slot its cubie came from."""
+    from rubiks_cube_solver_amd import _lib
+    from rubiks_cube_solver_amd.tables import get_tables
+    for cs, nf_want in ((3, 51), (2, 15)):
+        nf, rows = _lib.family_layout(cs)
+        t = get_tables(cs)
+        A, SL, NC = len(t.perm), rows.shape[1], len(t.corner_defs)
+        assert nf == nf_want and rows.shape == (A + 1, SL)
+        assert len(set(rows[A].tolist())) == SL                                   # the parent's slots: SL different look-ups
+        assert set(rows.reshape(-1).tolist()) == set(range(nf))                   # no unused row, none out of range
+        assert (rows[:, :NC] < rows[A, :NC].max() + 6).all() and (rows[:, NC:] > rows[:, :NC].max()).all() if SL > NC else True
+        for a in range(A):                                                        # slots a turn does not touch keep the parent's row
+            moved = set(int(i) for i in np.nonzero(np.asarray(t.perm[a]) != np.arange(len(t.perm[a])))[0])
+            for p_, d in enumerate(list(t.corner_defs) + list(t.edge_defs)):
+                if not (set(int(x) for x in d) & moved):
+                    assert rows[a, p_] == rows[A, p_], (cs, a, p_)
 
 
 def test_product_code_never_injects_a_backend():

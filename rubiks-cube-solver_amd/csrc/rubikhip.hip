@@ -1312,14 +1312,18 @@ Geometry pick_geometry(int64_t n, int A, int variant, bool stickers_out, int64_t
 // (three repeats, profiles/r03_ab.json): 8 walks per lane x 3 segments (588 waves) 148-149 us every time, 4 walks per lane x
 // 2 segments (782 waves) 146-160 us, round 2's 4 walks per lane x 2 parts 162-166 us; more segments lose to the replayed
 // moves.  Rule: about 600 waves; wide packs once that still leaves >= 2 segments' worth of groups.
-Geometry pick_geometry_adi(int64_t n, int A, int variant, bool stickers_out, int64_t out_bytes, bool codes) {
+// FAMILY records (118 B per state instead of 327): with a third of the stores the launch is VALU-bound and wants MORE, narrower
+// waves -- 4 walks per lane and about 1560 waves (100k x 30: 82 us against 109 us with 8 walks per lane x 4 segments and 89 us x 5;
+// 1M x 4: 86 us against 103 us; profiles/r04_adi_family.json); small batches keep the 700-wave rule (20k x 30: 36 us).
+Geometry pick_geometry_adi(int64_t n, int A, int variant, bool stickers_out, int64_t out_bytes, bool codes, bool family = false) {
     Geometry g = pick_geometry(n, A, variant, stickers_out, out_bytes);
     if (codes && !stickers_out) {
         const int fv = variant % 10, fp = (variant / 1000) % 100;
-        g.v = fv == 1 || fv == 2 ? fv : (n >= 64 * kWave * 8 ? 2 : 1);
+        g.v = fv == 1 || fv == 2 ? fv : (n >= 64 * kWave * 8 && !family ? 2 : 1);
         g.parts = fp >= 1 && fp <= A ? g.parts : 1;
         const int64_t waves = (n + kWave * 4 * g.v - 1) / (kWave * 4 * g.v) * g.parts;
-        const int64_t segs = (600 + waves / 2) / (waves > 0 ? waves : 1);
+        const int64_t target = !family ? 600 : n >= 64 * kWave * 8 ? 1560 : 700;
+        const int64_t segs = (target + waves / 2) / (waves > 0 ? waves : 1);
         g.segs = segs < 1 ? 1 : segs > kMaxSegs ? kMaxSegs : (int)segs;
     }
     return g;
@@ -1644,9 +1648,8 @@ static int adi_common(uint64_t seed, uint64_t stream_id, int64_t walk_offset, in
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
         const bool any_child = children || child_code || child_solved;
-        Geometry geo = pick_geometry_adi(n_walks, T::A, variant, children != nullptr, n_walks * depth * T::S * T::A, parent_code || child_code || family);
+        Geometry geo = pick_geometry_adi(n_walks, T::A, variant, children != nullptr, n_walks * depth * T::S * T::A, parent_code || child_code || family, family != nullptr);
         if (!any_child && (variant / 1000) % 100 == 0) geo.parts = 1;
-        if (family && (variant / 1000000) % 100 == 0 && geo.segs > 1) geo.segs += 1;   // fewer stores per emitted depth: one more segment (64 against 71 us at 100k x 30)
         AdiArgs a{seed, stream_id, walk_offset, n_walks, pitch, n_walks <= pitch ? 1 : (n_walks + pitch - 1) / pitch, depth,
                   geo.parts, sh, actions_in, actions_out, parents, parent_code, children, child_code, child_solved, family, 1, {}};
         if (depth > 0xffff) return fail(RC_EINVAL, "rc_adi_generate: depth must be below 65536%s");
@@ -1873,8 +1876,7 @@ int rc_describe_dispatch(int op, int cube_size, int64_t n, int depth, unsigned o
         if (op == RC_OP_ADI) {
             if (depth <= 0) return fail(RC_EINVAL, "rc_describe_dispatch: depth must be positive%s");
             const bool family = outputs & RC_OUT_FAMILY;
-            Geometry geo = pick_geometry_adi(n, T::A, variant, states, n * depth * T::S * T::A, code || family);
-            if (family && (variant / 1000000) % 100 == 0 && geo.segs > 1) geo.segs += 1;
+            Geometry geo = pick_geometry_adi(n, T::A, variant, states, n * depth * T::S * T::A, code || family, family);
             const bool any_child = states || code || (outputs & RC_OUT_FLAGS);
             if (!any_child && (variant / 1000) % 100 == 0) geo.parts = 1;
             AdiArgs a{};

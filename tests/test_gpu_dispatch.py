@@ -303,7 +303,7 @@ def test_adi_codes_default_dispatch_100k(ops, L, oracle):
             assert (got[12] == exp["parent_code"][:, d]).all() and (got[:12].transpose(1, 0, 2) == exp["child_code"][:, d]).all(), (dt, d)
             assert float(dense.view(13, p, 20, 24)[:, :W].float().sum()) == 13.0 * 20 * W
             assert float(dense.view(13, p, 20, 24)[:, W:].float().min()) == 3.0 if p > W else True       # pad cubes untouched
-    assert "k_adi<Cube3,V=2,code,family> parts=1 segs=4" in L.describe(L.OP_ADI, cs, W, 30, outputs=L.OUT_FAMILY | L.OUT_FLAGS)
+    assert "k_adi<Cube3,V=1,code,family> parts=1 segs=4 grid=1564" in L.describe(L.OP_ADI, cs, W, 30, outputs=L.OUT_FAMILY | L.OUT_FLAGS)
     assert L.read_status() == 0
 
 

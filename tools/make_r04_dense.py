@@ -118,6 +118,18 @@ def main():
                            "1 or 2 fronts per XCD per workgroup).  Session n, final kernels; the dispatch thresholds in dense_form / dense_workspace_bytes come from here "
                            "(an earlier sweep, session h, showed the workspace route at 0.52 from 2^21 cubes while its code was streamed past the cache: RowPolicy<4>)",
                    "rows": rs}, open(os.path.join(ROOT, "profiles", "r04_dense_sizes.json"), "w"), indent=1)
+    a, b = rows("r04s_adi_probe.jsonl"), rows("r04u_fam_probe.jsonl")
+    if a or b:
+        json.dump({"what": "code-emitting ADI at 100k walks x 30 (and 20k x 30, 1M x 4): which outputs cost what, and the launch geometry of the FAMILY record "
+                           "(HIP-event microseconds per launch; variant digits: units = pack width V, millions = depth segments; kernel = rc_describe_dispatch)",
+                   "outputs_probe_session_s": a,
+                   "outputs_reading": "parent stickers + parent codes + flags WITHOUT the 12 x 20 child-code rows: 75.7 us against 181.9 us with them -- the family look-ups "
+                                      "are computed either way, the child codes are pure store traffic (240 of 327 B per state)",
+                   "family_geometry_session_u": b,
+                   "family_reading": "with a third of the stores the launch is VALU-bound and wants more, narrower waves: 4 walks per lane x 4 segments (1564 waves) 82.4 us at "
+                                     "100k x 30 against 108.6 us for 8 walks per lane x 4 and 89.4 us x 5; 1M x 4: 85.9 us (4 walks per lane) against 102.9 us; 20k x 30: "
+                                     "36 us with the small-batch rule (9 segments).  Shipped: V = 1, about 1560 waves (pick_geometry_adi)"},
+                  open(os.path.join(ROOT, "profiles", "r04_adi_family.json"), "w"), indent=1)
     print("wrote profiles/r04_dense_control.json", os.path.getsize(os.path.join(ROOT, "profiles", "r04_dense_control.json")), "bytes")
 
 

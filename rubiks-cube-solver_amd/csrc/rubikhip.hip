@@ -567,8 +567,9 @@ struct AdiArgs {
 // < seg_lo[s] without any output (RNG + move: ~1/5 of a full depth with codes), then emits its own depths.  Code-only
 // generation is VALU-bound with one wave per 256 walks (fewer waves than SIMDs at 100k walks): depth segments fill the chip
 // without duplicating the code look-ups the way `parts` does.
-template <class T, int V, bool CODE>
+template <class T, int V, bool CODE, bool FAM = false>
 __global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
+    static_assert(CODE || !FAM, "the family record is made of the code look-ups");
     const int64_t item = blockIdx.x;
     const int ps = a.parts * a.segs;
     const int64_t g = item / ps;
@@ -646,8 +647,8 @@ __global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
 #pragma unroll
                 for (int i = 0; i < T::S; ++i) bst<V, RC_OUT_AUX>(r, lo, i * rs, s[i]);
             }
-            if constexpr (CODE) {
-                if (a.family) {
+            if constexpr (FAM) {
+                {
                     // the FAMILY record: every used (slot, reading order) look-up as a row of its own -- 51 bytes per state instead of the
                     // 13 x 20 picked codes; rc_onehot_from_family does the per-child pick when it expands to dense
                     constexpr int NF = kFamily<T>.nf;
@@ -667,6 +668,8 @@ __global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
                         });
                     });
                 }
+            }
+            if constexpr (CODE && !FAM) {
                 if (a.parent_code) {
                     Pk<V> pc[T::SLOTS];
                     family_pick<T, V, -1>(fam, pc);
@@ -680,7 +683,7 @@ __global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
                          a.child_solved ? a.child_solved + (int64_t)d * T::A * wp + g0 : nullptr,
                          a.child_code ? a.child_code + (int64_t)d * T::A * T::SLOTS * wp + code_off : nullptr,
                          rs, a.tiles, flags_live};
-        if (CODE && co.child_code != nullptr) emit_children<T, V, CODE, true>(s, fam, cf, part, a.parts, co, lo);
+        if (CODE && !FAM && co.child_code != nullptr) emit_children<T, V, CODE && !FAM, true>(s, fam, cf, part, a.parts, co, lo);
         else emit_children<T, V, false, true>(s, fam, cf, part, a.parts, co, lo);
     }
 }
@@ -1392,7 +1395,8 @@ int launch_adi(AdiArgs a, hipStream_t st) {
     const int64_t groups = (a.n_walks + kWave * 4 * V - 1) / (kWave * 4 * V);
     RC_GRID(groups * a.parts * a.segs);
     const dim3 g((unsigned)(groups * a.parts * a.segs)), b(kWave);
-    if (a.parent_code || a.child_code || a.family) hipLaunchKernelGGL((k_adi<T, V, true>), g, b, 0, st, a);
+    if (a.family) hipLaunchKernelGGL((k_adi<T, V, true, true>), g, b, 0, st, a);      // (adi_common: no codes beside the family record)
+    else if (a.parent_code || a.child_code) hipLaunchKernelGGL((k_adi<T, V, true>), g, b, 0, st, a);
     else hipLaunchKernelGGL((k_adi<T, V, false>), g, b, 0, st, a);
     RC_HIP(hipGetLastError());
     return RC_OK;

@@ -68,7 +68,7 @@ for i in range(1, 6):
     fresh.append(row)
 if fresh:
     W, D = 100_000, 30
-    key = "k_adi<rc::Cube3, 2, false>"
+    key = "k_adi<rc::Cube3, 2, false, false>"
     avgs = [r[key]["avg_us"] for r in fresh if key in r]
     json.dump({"command": "rocprofv3 --kernel-trace --stats -- python3 tools/microbench.py adi expand   (x5, a fresh process each)",
                "workload": "k_adi: 100000 walks x depth 30, parents + 12 children + flags + actions, default dispatch and tiling; "

@@ -138,6 +138,9 @@ def main():
         path = os.path.join(CTL, f"librubikhip_{name}.so")
         if os.path.exists(path) and (not args.quick or name == "gather"):
             L = ctypes.CDLL(path)
+            if not hasattr(L, "rc_onehot_from_family"):
+                print(f"# {path} is a build of older sources: rebuild with --build", file=sys.stderr)
+                continue
             _lib._declare(L)
             assert L.rc_init(0) == 0
             libs[name] = L

@@ -46,11 +46,14 @@ def init(backend=None, device=None):
     """Initialise the default process group when launched with WORLD_SIZE > 1 (reporting only)."""
     rank, ws, local = world()
     if ws > 1 and not dist.is_initialized():
-        if _TOO_LATE and (backend or "nccl") == "nccl":
-            raise RuntimeError("HSA_ENABLE_IPC_MODE_LEGACY=0 must be exported (or this module imported) before the process first "
-                               "touches the GPU: RCCL needs dmabuf IPC here")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            # the import-time flag catches "set too late"; the live value catches an explicitly exported value other than 0 (which the
+            # setdefault above leaves alone) -- either way RCCL would start in legacy IPC mode and fail in hipIpcGetMemHandle
+            if _TOO_LATE or os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
+                raise RuntimeError("HSA_ENABLE_IPC_MODE_LEGACY=0 must be exported (or this module imported) before the process first "
+                                   f"touches the GPU: RCCL needs dmabuf IPC here (now: {os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')!r})")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {}
         if backend == "nccl" and device is not None:
             kw["device_id"] = device

@@ -458,6 +458,18 @@ def test_two_rank_gloo_sharding(tmp_path):
     assert r0["first_actions"] == Oracle().rng_actions(77, 0, 0, 6, 12).tolist()  # reproducible
 
 
+def test_dist_init_refuses_legacy_ipc_for_nccl(monkeypatch):
+    """dist.init for the nccl backend refuses an exported HSA_ENABLE_IPC_MODE_LEGACY other than 0: no process group
+    is created, nothing touches a GPU."""
+    from rubiks_cube_solver_amd import dist as d
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "1")
+    with pytest.raises(RuntimeError, match="HSA_ENABLE_IPC_MODE_LEGACY"):
+        d.init(backend="nccl")
+    assert not d.dist.is_initialized()
+
+
 def test_eight_rank_streams_and_shards(tmp_path):
     """BASELINE config 4's world size (8 ranks) on CPU over gloo: eight contiguous shards that tile the batch, eight RNG streams
     that are each the oracle's (seed, stream_id = rank) stream and pairwise different, SUM / MAX reductions over all eight.

@@ -230,7 +230,7 @@ def other_configs(torch, ops, _lib, dev, acts):
             "ops.apply_moves = rc_apply_moves_ws: ONE call, two launches (step + reward + done + compact code into a caller-owned workspace, "
             "then the front writer: one 3840-byte pass per workgroup)")
         del oh
-    # compact code -> dense one-hot: what adi_samples, the replay sink and the lockstep search launch (the wide writer)
+    # compact code -> dense one-hot: what the replay sink and the lockstep search launch (the front writer; adi_samples uses its family form)
     code1 = ops.alloc_code(m, CUBE, dev)
     ops.encode(a1, m, CUBE, code1, _lib.FMT_CODE)
     for dt, fmt, name, bpc in ((torch.float32, _lib.FMT_F32, "f32", 1920), (torch.bfloat16, _lib.FMT_BF16, "bf16", 960)):

@@ -286,10 +286,11 @@ const char *rc_last_error(void);
  *   hundreds   streaming expansion (stickers + flags by few persistent waves): 1..7 -> 128, 192, 256, 384, 512, 768, 1024 waves, 8 -> off
  *   thousands  (2 digits) parts per walk group for expansion / ADI (1..A, rounded up to a divisor of A)
  *   100000s    dense one-hot writer: 1 -> 64-cube tiles, 2 -> 256-cube tiles (256-thread workgroups), 3 -> the wide form of
- *              rc_onehot_from_code (960-thread workgroups sweeping contiguous tile ranges; 3x3x3; the thousands field then gives
- *              the wanted workgroup count / 16, the tens digit the sweep skew), 4 -> the front form of rc_onehot_from_code
- *              (one 3840-byte pass per workgroup; 3x3x3, the default from 2^17 cubes; tens digit 2 -> one linear front instead
- *              of one front per XCD).  Any non-zero value makes rc_apply_moves_ws ignore its workspace.
+ *              rc_onehot_from_code (960-thread workgroups sweeping contiguous tile ranges; 3x3x3, superseded, kept for A/B; the
+ *              thousands field then gives the wanted workgroup count / 16, the tens digit the sweep skew), 4 -> the front form of
+ *              rc_onehot_from_code (one 3840-byte pass per workgroup; 3x3x3; the default from 2^15 / 2^16 / 2^18 cubes for f32 /
+ *              16-bit / u8): units digit 1, 2, 4 = fronts per XCD per workgroup, tens digit 2 = one linear front, 3 = code bytes by
+ *              a gather per lane, 4 = by one load of wave 0 + LDS.  Any non-zero value makes rc_apply_moves_ws ignore its workspace.
  *   millions   (2 digits) depth segments per walk group of the ADI kernel (1..16, clamped to depth) */
 
 #ifdef __cplusplus

@@ -73,6 +73,27 @@ float run_block(unsigned char *buf, long long bytes, const unsigned char *side, 
     return ms / iters * 1e3f;
 }
 
+// Row-copy front (the sticker expansion as pure data movement): out[a][tile][row][:] = in[tile][(row * 5 + a) % 54][:], A = 12 children,
+// 54 rows of P bytes per tile.  One 4-KiB pass per workgroup; blocks b, b + 8, ... (one XCD) walk the passes of that XCD's tiles in
+// the order (tile, a, row, segment), so a tile's 54 rows are read from HBM once and found in the XCD's L2 by the other 11 children.
+template <int AUX>
+__global__ void __launch_bounds__(256) k_copy_front(const unsigned char *in, unsigned char *out, int tiles, int P, long long per_xcd) {
+    const int segs = P / 4096;
+    const long long local = blockIdx.x >> 3;                                   // pass index inside this XCD's list
+    const int xcd = blockIdx.x & 7;
+    if (local >= per_xcd) return;
+    const long long per_tile = 12ll * 54 * segs;
+    const int tl = (int)(local / per_tile);                                     // the XCD's tl-th tile = global tile tl * 8 + xcd
+    const int tile = tl * 8 + xcd;
+    if (tile >= tiles) return;
+    long long r = local - (long long)tl * per_tile;
+    const int a = (int)(r / (54 * segs)); r -= (long long)a * 54 * segs;
+    const int row = (int)(r / segs), seg = (int)(r - (long long)row * segs);
+    const int srow = (row * 5 + a) % 54;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(make_srd(in + ((long long)tile * 54 + srow) * P + (long long)seg * 4096), threadIdx.x * 16u, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, make_srd(out + (((long long)a * tiles + tile) * 54 + row) * P + (long long)seg * 4096), threadIdx.x * 16u, 0, AUX);
+}
+
 template <int AUX, int LANES>
 float run(unsigned char *buf, long long bytes, long long chunk, int grid, hipStream_t st, int iters) {
     const long long nchunks = (bytes + chunk - 1) / chunk;
@@ -109,6 +130,35 @@ int main(int argc, char **argv) {
     unsigned char *side;
     CK(hipMalloc(&side, side_pitch * 20));
     CK(hipMemset(side, 1, side_pitch * 20));
+    if (argc > 3) {   // mode "copy": the row-copy front at 2^20 parents (32 tiles of 32768), against a fill of the same 679 MB output
+        const int tiles = 32, P = 32768;
+        const long long obytes = 12ll * tiles * 54 * P, ibytes = (long long)tiles * 54 * P;
+        unsigned char *in;
+        CK(hipMalloc(&in, ibytes));
+        CK(hipMemset(in, 3, ibytes));
+        const long long per_xcd = (tiles / 8) * 12ll * 54 * (P / 4096);
+        for (int b = 0; b < nb; ++b) {
+            for (int rep = 0; rep < 3; ++rep) {
+                hipEvent_t e0, e1;
+                CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+                for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((k_copy_front<19>), dim3((unsigned)(per_xcd * 8)), dim3(256), 0, st, in, bufs[b], tiles, P, per_xcd);
+                CK(hipEventRecord(e0, st));
+                for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k_copy_front<19>), dim3((unsigned)(per_xcd * 8)), dim3(256), 0, st, in, bufs[b], tiles, P, per_xcd);
+                CK(hipEventRecord(e1, st));
+                CK(hipEventSynchronize(e1));
+                CK(hipGetLastError());
+                float ms = 0;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                const float us = ms / iters * 1e3f;
+                printf("{\"what\": \"copy_front\", \"buf\": %d, \"us\": %.1f, \"frac_written_plus_read_once\": %.4f, \"frac_written_only\": %.4f}\n", b, us,
+                       (obytes + ibytes) / (us * 1e-6) / 8e12, obytes / (us * 1e-6) / 8e12);
+                fflush(stdout);
+            }
+            const float t = run_block<19, 256, 256, false>(bufs[b], obytes, side, side_pitch, true, st, iters);
+            printf("{\"what\": \"fill_same_bytes\", \"buf\": %d, \"us\": %.1f, \"frac_written_only\": %.4f}\n", b, t, obytes / (t * 1e-6) / 8e12);
+        }
+        return 0;
+    }
     for (int b = 0; b < nb; ++b) {
         {
             for (int i = 0; i < 2; ++i) CK(hipMemsetAsync(bufs[b], 0, bytes, st));

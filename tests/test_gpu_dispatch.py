@@ -333,6 +333,11 @@ def test_adi_family_records_small_and_tiled(ops, L, oracle, cs, n, pitch, varian
         got = dense[:13 * p].view(13, p, 20, 24)[:, :n].float().argmax(-1).to(torch.uint8).cpu().numpy()
         assert (got[12] == exp["parent_code"][:, 2]).all() and (got[:12].transpose(1, 0, 2) == exp["child_code"][:, 2]).all()
         assert float(dense[13 * p:].float().min()) == 3.0
+        if n > 1:                                                                    # a block stride smaller than the batch is refused, nothing written
+            rc = L.lib().rc_onehot_from_family(L.ptr(fb["family"][2]), n, fb["family"].shape[-1], cs, L.ptr(dense), L.FMT_F16, n - 1, L.stream_ptr(dense.device))
+            assert rc == -1 and b"block_stride" in L.lib().rc_last_error()
+        rc = L.lib().rc_adi_generate_family(9, 2, 0, n, D, cs, pt, None, None, None, None, None, L.stream_ptr(dense.device), 0)
+        assert rc == -1 and b"family is NULL" in L.lib().rc_last_error()
     else:
         with pytest.raises(L.RubikHipError):
             ops.onehot_from_family(fb["family"][0], n, cs, torch.empty((7 * n + n, 7, 21), dtype=torch.float32, device="cuda"), block_stride=n)

@@ -67,6 +67,34 @@ def main():
             pmc[f"{name} | WRREQ={req}"] = {"dispatches": len(ds), "us_min_med_max": [round(us[0], 1), round(us[len(us) // 2], 1), round(us[-1], 1)],
                                             "stall_cycles_per_request_min_med_max": [round(st[0], 3), round(st[len(st) // 2], 3), round(st[-1], 3)],
                                             "bytes_64B_requests": req * 64}
+    pmc_a = pmc
+    pmc = {}
+    for f in glob.glob(os.path.join(G, "r04ad_pmc_wrreq", "*", "*counter_collection.csv")):
+        disp = collections.OrderedDict()
+        for r in csv.DictReader(open(f)):
+            d = disp.setdefault(r["Dispatch_Id"], {"k": r["Kernel_Name"], "us": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3})
+            d[r["Counter_Name"]] = float(r["Counter_Value"])
+        agg = collections.defaultdict(list)
+        for d in disp.values():
+            if d.get("TCC_EA0_WRREQ_sum", 0) > 1e6:
+                name = d["k"].replace("void (anonymous namespace)::", "").replace("void at::native::", "").split("(")[0][:60]
+                agg[(name, int(d["TCC_EA0_WRREQ_sum"]))].append(d)
+        for (name, req), ds in agg.items():
+            st = sorted(x["TCC_EA0_WRREQ_STALL_sum"] / x["TCC_EA0_WRREQ_sum"] for x in ds)
+            us = sorted(x["us"] for x in ds)
+            pmc[f"{name} | WRREQ={req}"] = {"dispatches": len(ds), "us_min_med_max": [round(us[0], 1), round(us[len(us) // 2], 1), round(us[-1], 1)],
+                                            "stall_cycles_per_request_min_med_max": [round(st[0], 3), round(st[len(st) // 2], 3), round(st[-1], 3)],
+                                            "bytes_64B_requests": req * 64}
+    if pmc:
+        out["pmc_TCC_EA0_WRREQ_session_ad_final_kernels"] = {
+            "what": "the same two counters over `tools/dense_control.py --pmc --quick` with the FINAL library (front writer in its shipped shapes, the superseded forms "
+                    "beside it), three buffers per format, durations under the profiler",
+            "per_kernel": pmc,
+            "reading": "the front writer is the FASTEST writer of each format (f32 276 us against 305 us for hipMemsetAsync and 299 us for the wide form of that session) and "
+                       "stalls LEAST at the L2's memory-side port (0.000-0.005 cycles per request; 2 / 4 fronts per workgroup: 0.03-0.39): stall cycles measure how bursty "
+                       "the request stream is, not how fast it runs -- a workgroup that issues one store per lane and ends gives the fabric a perfectly paced stream; "
+                       "fills (many stores per wave) and the tile sweepers (0.15-0.42) arrive in bursts"}
+    pmc = pmc_a
     out["pmc_TCC_EA0_WRREQ_session_a"] = {
         "what": "rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum -- python3 tools/dense_control.py --pmc (durations under the profiler)",
         "per_kernel": pmc,

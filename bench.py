@@ -233,7 +233,8 @@ def other_configs(torch, ops, _lib, dev, acts):
     # compact code -> dense one-hot: what the replay sink and the lockstep search launch (the front writer; adi_samples uses its family form)
     code1 = ops.alloc_code(m, CUBE, dev)
     ops.encode(a1, m, CUBE, code1, _lib.FMT_CODE)
-    for dt, fmt, name, bpc in ((torch.float32, _lib.FMT_F32, "f32", 1920), (torch.bfloat16, _lib.FMT_BF16, "bf16", 960)):
+    for dt, fmt, name, bpc in ((torch.float32, _lib.FMT_F32, "f32", 1920), (torch.bfloat16, _lib.FMT_BF16, "bf16", 960), (torch.float16, _lib.FMT_F16, "f16", 960),
+                               (torch.uint8, _lib.FMT_U8, "u8", 480)):
         oh = torch.empty((m, 20, 24), dtype=dt, device=dev)
         t = timed(lambda: ops.onehot_from_code(code1, m, CUBE, oh), 10, 2)
         rec(f"1M code->dense {name}", f"3x3x3 batch 1M, compact code -> dense {name} one-hot [N,20,24] (rc_onehot_from_code)", D(_lib.OP_CODE_TO_DENSE, CUBE, m, fmt=fmt), m, "cubes",
@@ -244,7 +245,27 @@ def other_configs(torch, ops, _lib, dev, acts):
     ex = ops.expand_buffers(m, CUBE, dev, children=True, codes=False)
     t = timed(lambda: ops.expand_children(a1, m, CUBE, ex["children"], ex["child_solved"], pitch=ex["children"].shape[-1]), 30)
     rec("1M expansion", "3x3x3 expansion of 1M parents to all 12 children + solved flags", D(_lib.OP_EXPAND, CUBE, m, outputs=ST | FLAGS), m, "parents", 54 + 12 * 54 + 12, t)
-    del ex, a1, b1, pp
+    del ex
+    oh8 = torch.empty((m, 20, 24), dtype=torch.uint8, device=dev)
+    t = timed(lambda: ops.apply_moves(a1, b1, acts, m, CUBE, rew, done, oh8, _lib.FMT_U8), 10, 2)
+    rec("1M step+dense u8", "3x3x3 batch 1M, apply_move + reward + done + fused dense u8 one-hot [N,20,24] (one launch: k_step_dense)",
+        D(_lib.OP_STEP, CUBE, m, outputs=ST | REW | _lib.OUT_WORKSPACE, fmt=_lib.FMT_U8), m, "steps", 114 + 480, t)
+    del oh8, a1, b1, pp
+    # 2x2x2 at 1M cubes: expansion to the 6 children (24 R + 6 * 24 W + 6 flags) and code -> dense f32 (7 R + 147 * 4 W)
+    s2 = ops.alloc_states(m, 2, dev)
+    ops.fill_solved(s2, m, 2)
+    ops.scramble(s2, m, 2, 14, seed=1234)
+    ex2 = ops.expand_buffers(m, 2, dev, children=True, codes=False)
+    t = timed(lambda: ops.expand_children(s2, m, 2, ex2["children"], ex2["child_solved"], pitch=ex2["children"].shape[-1]), 30)
+    rec("2x2x2 1M expansion", "2x2x2 expansion of 1M parents to all 6 children + solved flags", D(_lib.OP_EXPAND, 2, m, outputs=ST | FLAGS), m, "parents", 24 + 6 * 24 + 6, t)
+    del ex2
+    code2 = ops.alloc_code(m, 2, dev)
+    ops.encode(s2, m, 2, code2, _lib.FMT_CODE)
+    oh2 = torch.empty((m, 7, 21), dtype=torch.float32, device=dev)
+    t = timed(lambda: ops.onehot_from_code(code2, m, 2, oh2), 10, 2)
+    rec("2x2x2 1M code->dense f32", "2x2x2 batch 1M, compact code -> dense f32 one-hot [N,7,21] (rc_onehot_from_code)", D(_lib.OP_CODE_TO_DENSE, 2, m, fmt=_lib.FMT_F32), m, "cubes",
+        7 + 147 * 4, t)
+    del s2, code2, oh2
     # config 3: ADI data generation
     W, DEPTH = 100_000, 30
     pt, ab = ops.adi_buffers(W, DEPTH, CUBE, dev, parents=True, children=True)
@@ -257,20 +278,20 @@ def other_configs(torch, ops, _lib, dev, acts):
     rec("ADI 100k x 30 codes", "ADI 100k x 30 with compact codes instead of child stickers (parent stickers + 13 codes + flags + actions)", D(_lib.OP_ADI, CUBE, W, DEPTH, outputs=CODE | FLAGS),
         W * DEPTH, "walk-depths", 54 + 1 + 12 + 13 * 20, t, f"output tiles of {pt} walks")
     del ab
-    pt, ab = ops.adi_buffers(W, DEPTH, CUBE, dev, parents=True, family=True)
+    pt, ab = ops.adi_buffers(W, DEPTH, CUBE, dev, family=True)
     t = timed(lambda: ops.adi_generate(W, DEPTH, CUBE, pt, dev, seed=2024, **ab), 10, 3)
-    rec("ADI 100k x 30 family", "ADI 100k x 30 with the 51-byte FAMILY record instead of the 13 codes (parent stickers + 51 shared look-ups + flags + actions): "
-        "what adi_samples launches", D(_lib.OP_ADI, CUBE, W, DEPTH, outputs=_lib.OUT_FAMILY | FLAGS), W * DEPTH, "walk-depths", 54 + 1 + 12 + 51, t,
-        f"output tiles of {pt} walks; 118 B per (walk, depth) against 327 B with the picked codes: the launch is VALU-bound, read the time, not the fraction")
+    rec("ADI 100k x 30 family", "ADI 100k x 30 as adi_samples launches it: the 51-byte FAMILY record (the shared look-ups behind the 13 codes) + child flags + actions, "
+        "no stickers", D(_lib.OP_ADI, CUBE, W, DEPTH, outputs=_lib.OUT_FAMILY | FLAGS), W * DEPTH, "walk-depths", 51 + 12 + 1, t,
+        f"output tiles of {pt} walks; 64 B per (walk, depth) against 327 B with the picked codes: the launch is VALU-bound, read the time, not the fraction")
     del ab
     torch.cuda.empty_cache()
     out = {"records": recs, "hbm_only_frac": hbm_only["roofline"]["frac"]}
-    try:                                                           # config 5 (latency-bound: microseconds, not GB/s)
-        from tools.bench_cfg5 import run as cfg5
-        r5 = cfg5(short=True)
-        out["config5_mcts_4096_leaves"] = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in r5.items()}
+    try:                                                           # config 5 (latency-bound: microseconds, not GB/s) + the lockstep search's whole simulation
+        from tools.bench_cfg5 import rounded, run as cfg5
+        out["config5_mcts_4096_leaves"] = rounded(cfg5(short=True))
     except Exception as e:
         out["config5_mcts_4096_leaves"] = {"error": str(e)[:200]}
+    out.update(pipeline_configs(torch, ops, _lib, dev))
     try:                                                           # batch-1 facade (the reference-shaped CubeEnv.step)
         import numpy as np
         import rubiks_cube_solver_amd as rc
@@ -306,6 +327,61 @@ def other_configs(torch, ops, _lib, dev, acts):
                                                  "note": "2x2x2 values are unpinned (the reference ships no py222): plumbing only"}
     except Exception as e:
         out["facade_batch1"] = {"error": str(e)[:200]}
+    return out
+
+
+def pipeline_configs(torch, ops, _lib, dev):
+    """End-to-end figures of the loops the reference actually runs (outside the timed region, a few seconds in all), wall-clock with
+    a synchronisation on both sides:
+      adi_pipeline   get_random_samples batched (adi.adi_samples: walks + expansion + one-hots + DeepCube forward + targets) at the
+                     reference's own size 200 x 30 (config/config.yaml:7-8, train.py:152-155), 20k x 30 and config 3's 100k x 30
+      rollout        greedy validation rollouts (train.py:167-198): microseconds per time step at n = 300 and 65536
+      reset_seeds    VecCubeEnv.reset(seeds=..., 30): numpy's legacy MT19937 draws on the device + the scramble, 1M envs"""
+    out = {}
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from tools.bench_adi_pipeline import run as adi_run
+        from tools.bench_cfg5 import DeepCubeStandIn
+        model = DeepCubeStandIn().to(dev).eval()
+        ap = adi_run(reps=3, model=model, dev=dev)
+        ap["200x30_hipgraph"] = adi_run(sizes=((200, 30),), reps=5, graph=True, model=model, dev=dev)["200x30"]
+        ap["note"] = ("median wall time of one adi_samples call incl. its final synchronisation; net = random-init DeepCube [1024,256,128] in float32 (the reference's "
+                      "config); the reference does 393 samples/s on one CPU core (SURVEY.md section 6)")
+        out["adi_pipeline"] = ap
+    except Exception as e:
+        out["adi_pipeline"] = {"error": str(e)[:200]}
+    try:
+        from tools.bench_rollout import run_all
+        out["rollout"] = run_all(T=100, model=model)
+        out["rollout"]["note"] = "greedy_rollout, 100 time steps from 15-move scrambles, random-init DeepCube: one net forward + one rc_apply_moves per time step"
+    except Exception as e:
+        out["rollout"] = {"error": str(e)[:200]}
+    try:
+        import rubiks_cube_solver_amd as rc
+        n, k = 1 << 20, 30
+        env = rc.VecCubeEnv(n, dev, CUBE, obs=None)
+        seeds = torch.arange(n, dtype=torch.int64) * 10                # train.py:180 seeds i * 10
+        seeds_dev = seeds.to(dev)
+        env.reset(seeds=seeds_dev, scramble_count=k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            env.reset(seeds=seeds_dev, scramble_count=k)
+        torch.cuda.synchronize()
+        whole = (time.perf_counter() - t0) / 5
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(5):
+            ops.legacy_scramble_actions(seeds_dev, CUBE, k, device=dev)
+        ev[1].record()
+        torch.cuda.synchronize()
+        out["reset_seeds_1M_k30"] = {"envs": n, "scramble_count": k, "reset_ms": whole * 1e3, "legacy_actions_us": ev[0].elapsed_time(ev[1]) / 5 * 1e3,
+                                     "resets_per_s": n / whole,
+                                     "note": "VecCubeEnv.reset(seeds=[...], 30): np.random.seed(s); randint(12, size=30) per env regenerated on the device "
+                                             "(rc_legacy_scramble_actions: streaming MT19937 + fix-up) then rc_scramble; cube_env.py:62-68"}
+        del env
+    except Exception as e:
+        out["reset_seeds_1M_k30"] = {"error": str(e)[:200]}
     return out
 
 
@@ -369,8 +445,14 @@ def main():
         # checked before anything touches the GPU: an exported value other than 0 would send RCCL into legacy IPC mode
         sys.exit("HSA_ENABLE_IPC_MODE_LEGACY must be 0 for RCCL on this driver stack (dmabuf IPC); it is "
                  f"{os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')!r}")
+    # RC_BENCH_DRY=1: the plumbing of the N-rank line without a GPU (process group, shards, barrier, all_gather, MAX over ranks, the
+    # JSON keys) -- no kernel is launched and `value` means nothing; tests/test_bench_contract.py runs the 8-rank shape this way
+    dry = os.environ.get("RC_BENCH_DRY") == "1"
+    if dry and args.backend != "gloo":
+        sys.exit("RC_BENCH_DRY=1 needs --backend gloo (no GPU is touched)")
     dev_index = local_rank % max(1, torch.cuda.device_count())      # one rank per GPU (rehearsals may share one)
-    torch.cuda.set_device(dev_index)
+    if not dry:
+        torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if use_dist:
         # reporting only (barrier + MAX of elapsed time): the env path itself has no collective
@@ -386,60 +468,82 @@ def main():
 
     n = args.cubes_per_gpu
     stream_id = rcdist.rng_stream(rank)                              # rank-distinct RNG stream, no exchange between ranks
-    a = ops.alloc_states(n, CUBE, dev)
-    b = torch.empty_like(a)
-    ops.fill_solved(a, n, CUBE)
-    ops.scramble(a, n, CUBE, SCRAMBLE_DEPTH, seed=SCRAMBLE_SEED, stream_id=stream_id)   # 20-move scrambles, rank-distinct streams
     k = min(n, SAMPLE_CUBES)
-    sample_sha = hashlib.sha256(ops.to_aos(a, k).contiguous().cpu().numpy().tobytes()).hexdigest()
-    g = torch.Generator(device=dev).manual_seed(1 + rank)
-    acts = torch.randint(0, 12, (n,), generator=g, device=dev, dtype=torch.uint8)
-    done = torch.empty(n, dtype=torch.uint8, device=dev)
-    bufs = [a, b]
+    if dry:
+        device_name, sample_sha = "dry run (no GPU)", "dry-run"
 
-    def step():
-        ops.apply_moves(bufs[0], bufs[1], acts, n, CUBE, None, done)
-        bufs.reverse()
+        def step():
+            pass
 
-    def sync_all():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    sync_all()
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
-        step()
-    e1.record()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1)                                     # HIP events on the launch stream
-    assert _lib.read_status(dev) == 0
-    # The roofline's launch duration: R more batches of `steps` launches each, back to back, every batch bracketed by HIP events on
-    # the launch stream (outside the timed region above, same buffers, same kernel): the MEDIAN batch is roofline.launch_us, so a
-    # 20-step driver run does not hang the headline fraction on one 1.4 ms sample.
-    n_batches = args.batches if args.batches > 0 else max(7, -(-140 // max(1, args.steps)))
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_batches + 1)]
-    evs[0].record()
-    for bi in range(n_batches):
+        def sync_all():
+            if use_dist:
+                dist.barrier()
+        for _ in range(args.warmup):
+            step()
+        sync_all()
+        t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-        evs[bi + 1].record()
-    torch.cuda.synchronize()
-    batch_us = sorted(evs[i].elapsed_time(evs[i + 1]) / args.steps * 1e3 for i in range(n_batches))
-    launch_us, launch_min, launch_max = batch_us[len(batch_us) // 2], batch_us[0], batch_us[-1]
-    assert _lib.read_status(dev) == 0
+        sync_all()
+        elapsed = max(time.perf_counter() - t0, 1e-9)
+        dev_ms = elapsed * 1e3
+        n_batches = args.batches if args.batches > 0 else max(7, -(-140 // max(1, args.steps)))
+        launch_us = launch_min = launch_max = elapsed / args.steps * 1e6
+    else:
+        device_name = torch.cuda.get_device_name(dev_index)
+        a = ops.alloc_states(n, CUBE, dev)
+        b = torch.empty_like(a)
+        ops.fill_solved(a, n, CUBE)
+        ops.scramble(a, n, CUBE, SCRAMBLE_DEPTH, seed=SCRAMBLE_SEED, stream_id=stream_id)   # 20-move scrambles, rank-distinct streams
+        sample_sha = hashlib.sha256(ops.to_aos(a, k).contiguous().cpu().numpy().tobytes()).hexdigest()
+        g = torch.Generator(device=dev).manual_seed(1 + rank)
+        acts = torch.randint(0, 12, (n,), generator=g, device=dev, dtype=torch.uint8)
+        done = torch.empty(n, dtype=torch.uint8, device=dev)
+        bufs = [a, b]
+
+        def step():
+            ops.apply_moves(bufs[0], bufs[1], acts, n, CUBE, None, done)
+            bufs.reverse()
+
+        def sync_all():
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            step()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sync_all()
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(args.steps):
+            step()
+        e1.record()
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        dev_ms = e0.elapsed_time(e1)                                     # HIP events on the launch stream
+        assert _lib.read_status(dev) == 0
+        # The roofline's launch duration: R more batches of `steps` launches each, back to back, every batch bracketed by HIP events on
+        # the launch stream (outside the timed region above, same buffers, same kernel): the MEDIAN batch is roofline.launch_us, so a
+        # 20-step driver run does not hang the headline fraction on one 1.4 ms sample.
+        n_batches = args.batches if args.batches > 0 else max(7, -(-140 // max(1, args.steps)))
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_batches + 1)]
+        evs[0].record()
+        for bi in range(n_batches):
+            for _ in range(args.steps):
+                step()
+            evs[bi + 1].record()
+        torch.cuda.synchronize()
+        batch_us = sorted(evs[i].elapsed_time(evs[i + 1]) / args.steps * 1e3 for i in range(n_batches))
+        launch_us, launch_min, launch_max = batch_us[len(batch_us) // 2], batch_us[0], batch_us[-1]
+        assert _lib.read_status(dev) == 0
     per_rank = None
     if use_dist:
         t = torch.tensor([elapsed, dev_ms, launch_us, launch_min, launch_max], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)                                     # reporting only: per-GPU figures beside the aggregate (config 4)
         shas = [None] * world
-        dist.all_gather_object(shas, {"stream_id": stream_id, "sha": sample_sha, "device": torch.cuda.get_device_name(dev_index)})
+        dist.all_gather_object(shas, {"stream_id": stream_id, "sha": sample_sha, "device": device_name})
         per_rank = [{"rank": r, "stream_id": shas[r]["stream_id"], "ms_per_step": float(x[0]) / args.steps * 1e3,
                      "launch_us": float(x[2]), "launch_us_timed_region": float(x[1]) / args.steps * 1e3, "steps_per_s": n * args.steps / float(x[0]),
                      "GBps": BYTES_PER_STEP * n / (float(x[2]) * 1e-6) / 1e9,
@@ -456,18 +560,20 @@ def main():
         return
 
     # the measured device-copy ceiling SURVEY 8d asks for beside the vendor peak: the runtime's own D2D copy of the same buffers
-    for _ in range(3):
-        bufs[1].copy_(bufs[0])
-    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    c0.record()
-    for _ in range(20):
-        bufs[1].copy_(bufs[0])
-    c1.record()
-    torch.cuda.synchronize()
-    copy_gbps = 2 * bufs[0].numel() / (c0.elapsed_time(c1) / 20 * 1e-3) / 1e9
+    copy_gbps = None
+    if not dry:
+        for _ in range(3):
+            bufs[1].copy_(bufs[0])
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(20):
+            bufs[1].copy_(bufs[0])
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 2 * bufs[0].numel() / (c0.elapsed_time(c1) / 20 * 1e-3) / 1e9
     kernel = _lib.describe(_lib.OP_STEP, CUBE, n, outputs=_lib.OUT_STATES | _lib.OUT_DONE)   # what the headline launches, from the library's own dispatch
     configs = None
-    if not args.no_configs:
+    if not args.no_configs and not dry:
         del a, b, bufs
         torch.cuda.empty_cache()
         configs = other_configs(torch, ops, _lib, dev, acts)
@@ -501,13 +607,18 @@ def main():
         "metric": "cube-move steps/sec, 3x3x3 batch 4M; HBM GB/s vs roofline at 1/2/4/8 GPU",
         "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic" if not dry else "synthetic (RC_BENCH_DRY=1: NO kernel ran, the numbers mean nothing)",
         "config": {"workload": workload, "cubes_per_gpu": n, "total_cubes": n * world, "bytes_per_step_algorithmic": BYTES_PER_STEP,
                    "parallelism": f"{world} independent ranks, stream_id = rank, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": kernel, "launch_us": launch_us, "launch_us_min": launch_min, "launch_us_max": launch_max,
                      "launch_us_timed_region": dev_ms / args.steps * 1e3,
+                     "frac_basis": "launch_us: the median event-timed batch AFTER the timed region (the kernel's steady launch duration)",
+                     "frac_timed_region": BYTES_PER_STEP * n / (dev_ms / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "frac_wall_clock": BYTES_PER_STEP * n / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS,
+                     "frac_note": "three durations, three fractions: frac (launch_us), frac_timed_region (HIP events around the K timed steps themselves), "
+                                  "frac_wall_clock (ms_per_step: host clock incl. the barrier and synchronisation on both sides = what `value` uses)",
                      "launch_batches": n_batches, "launches_per_batch": args.steps,
                      "launch_note": "launch_us = median over `launch_batches` back-to-back batches of `launches_per_batch` launches, each bracketed by "
                                     "HIP events on the launch stream, run right after the timed region (N > 1: the slowest rank's median)",
@@ -530,7 +641,9 @@ def main():
         out["roofline"]["aggregate_GBps"] = sum(r["GBps"] for r in per_rank)
         out["roofline"]["aggregate_frac_of_n_x_peak"] = out["roofline"]["aggregate_GBps"] / (HBM_PEAK_GBPS * world)
         out["config"]["process_group"] = args.backend
-    if not args.no_cpu and world == 1:
+    if dry:
+        out["dry_run"] = True
+    if not args.no_cpu and world == 1 and not dry:
         out["cpu_baseline"] = cpu_baseline()
     if configs:
         out["configs"] = configs

@@ -102,7 +102,7 @@ int rc_apply_moves(const uint8_t *in, uint8_t *out, const uint8_t *actions, int6
                    int64_t pitch_in, int64_t pitch_out, int cube_size, float *reward,
                    uint8_t *done, void *onehot, int fmt, int64_t code_pitch, void *stream);
 /* rc_apply_moves with a caller-owned WORKSPACE (device memory, 16-byte aligned, rc_workspace_bytes(RC_OP_STEP, ...) bytes; its
- * contents are scratch).  Results are identical to rc_apply_moves.  With a dense `fmt` on large 3x3x3 batches the workspace lets the
+ * contents are scratch; it must not overlap in, out, actions, reward, done or onehot: RC_EINVAL).  Results are identical to rc_apply_moves.  With a dense `fmt` on large 3x3x3 batches the workspace lets the
  * call run as two launches -- step + reward + done + compact code into the workspace, then the front writer
  * (k_code_to_dense_front) -- so that the dense stream leaves the chip as one sweeping window: 0.80-0.94 of the HBM peak on every
  * allocation instead of 0.67-0.87 depending on where the buffer lives (DESIGN.md "Dense one-hot").  A NULL or too small workspace,
@@ -145,9 +145,9 @@ int rc_facade_steps(uint8_t *st, int64_t pitch, int cube_size, const uint8_t *ac
 int rc_facade_expand(const uint8_t *st, int64_t pitch, int cube_size, uint8_t *host_out, uint32_t seq,
                      int dense, int wait, void *stream);
 
-/* The facade entry points cache, per calling thread, the device alias of the last host_out they validated, keyed on (host
- * address, current device); a call with seq == 1 (a caller's first use of a buffer) always validates afresh.  Call this before
- * freeing a host_out buffer (NULL drops whatever is cached); CubeEnv.close() / garbage collection does. */
+/* The facade entry points cache the device alias of every host_out they validated, process-wide, keyed on (host address, current
+ * device); a call with seq == 1 (a caller's first use of a buffer) always validates afresh.  Call this before freeing a host_out
+ * buffer, from ANY thread (NULL drops everything cached); CubeEnv.close() / garbage collection does. */
 int rc_facade_release(const uint8_t *host_out);
 
 /* `depth` moves applied in place to every cube: the scramble loop of CubeEnv.reset
@@ -167,6 +167,13 @@ int rc_scramble(uint8_t *st, int64_t n_cubes, int64_t pitch, int cube_size, int 
 int rc_legacy_scramble_actions(const uint32_t *seeds, const int32_t *counts, int count_uniform, int kmax,
                                int64_t n_envs, int cube_size, uint8_t *actions_out, int64_t pitch,
                                void *stream);
+/* Same with the generator form chosen by the caller (RC_VARIANT_LEGACY_*; 0 = rc_legacy_scramble_actions).  Two forms produce the
+ * same bytes: the LDS form keeps MT19937's 624-word state per env in LDS (any count; the twist is done lazily, 64 words at a time);
+ * the STREAMING form computes outputs 0..226 of the first generation from two init_genrand chain iterators in registers (no state at
+ * all) and is followed by a fix-up launch of the LDS form for the waves in which a lane needed more -- the default up to kmax = 128. */
+int rc_legacy_scramble_actions_ex(const uint32_t *seeds, const int32_t *counts, int count_uniform, int kmax,
+                                  int64_t n_envs, int cube_size, uint8_t *actions_out, int64_t pitch,
+                                  void *stream, int variant);
 
 /* done / reward of the given states, no move.  Replaces isSolved_3 (py333.py:229-233). */
 int rc_is_solved(const uint8_t *st, int64_t n_cubes, int64_t pitch, int cube_size,
@@ -242,10 +249,24 @@ int rc_adi_generate_family(uint64_t seed, uint64_t stream_id, int64_t walk_offse
 int rc_family_layout(int cube_size, uint8_t *rows, int32_t *n_rows);
 int rc_onehot_from_family(const uint8_t *family, int64_t n_cubes, int64_t pitch, int cube_size, void *onehot,
                           int fmt, int64_t block_stride, void *stream);
+/* The same for n_depths CONSECUTIVE depths of one rc_adi_generate_family call in one launch: `family` points at the first depth's
+ * record ([n_depths][tile][NF][pitch]); depth g, block a (child a; a = A: the parent) goes to onehot + (g * (A + 1) + a) * block_stride
+ * cubes -- the [depth][A + 1][block_stride] input of ONE forward of the value net (cube_env.py:239-251 evaluates it 2 x per sample). */
+int rc_onehot_from_family_depths(const uint8_t *family, int64_t n_cubes, int64_t pitch, int cube_size, void *onehot,
+                                 int fmt, int64_t block_stride, int n_depths, void *stream);
 
 int rc_adi_targets(const float *child_value, const uint8_t *child_solved, const float *parent_value,
                    const double *weight, int64_t n, int64_t pitch, int cube_size,
                    float *target_value, int32_t *target_policy, double *error, void *stream);
+/* The same rule for n_depths depths at once, reading the value net's output in place and writing WALK-MAJOR results (the layout of
+ * the replay sink, utils.py:253-260 one record per (cube, depth)):
+ *   child_value[g * cv_depth_stride + a * cv_child_stride + w], parent_value[g * pv_depth_stride + w]  (floats; strides in elements),
+ *   child_solved[(g * A + a) * solved_pitch + w]  (the [depth][A][Wp] flags of rc_adi_generate*),  weight[g] = (g0 + g + 1) ** -T,
+ *   target_value / target_policy / error [w * out_stride + g]   for w < n, g < n_depths  (out_stride >= n_depths). */
+int rc_adi_targets_depths(const float *child_value, int64_t cv_depth_stride, int64_t cv_child_stride,
+                          const uint8_t *child_solved, int64_t solved_pitch, const float *parent_value,
+                          int64_t pv_depth_stride, const double *weight, int64_t n, int n_depths, int cube_size,
+                          float *target_value, int32_t *target_policy, double *error, int64_t out_stride, void *stream);
 
 /* Read-and-clear the device status word: ONE atomic exchange on the device, ordered after the work queued
  * on `stream` (which it synchronises).  The word is per device, not per stream: a bit set by a kernel
@@ -259,7 +280,7 @@ int rc_read_status(uint32_t *status, void *stream);
  *   outputs  RC_OUT_* bits: STATES = the out buffer of a step (move + store) or the children stickers, CODE = compact codes,
  *            FLAGS = child_solved, REWARD / DONE = the step's reward / done arrays, INPLACE = out aliases in (step)
  *   fmt      the one-hot format of a step / code-to-dense call;  variant: the tuning override (0 = defaults)
- * Nothing is launched; no reference counterpart (tooling). */
+ * Nothing is launched; no reference counterpart (tooling).  `variant` must only use the RC_VARIANT_* fields of `op`'s group. */
 #define RC_OP_STEP 1
 #define RC_OP_EXPAND 2
 #define RC_OP_ADI 3
@@ -278,20 +299,40 @@ int rc_describe_dispatch(int op, int cube_size, int64_t n, int depth, unsigned o
 /* Message of the calling thread's last failed call ("" if none). */
 const char *rc_last_error(void);
 
-/* Tuning override of the *_ex entry points (benchmarks and tests that must reach every kernel
- * instantiation; there is NO process-global knob).  0 = the measured defaults.  Decimal digits:
- *   units      pack width: 1,2 -> 4,8 cubes per lane
- *   tens       row-traffic policy of the step kernel: 1 stream in / stream out, 2 default-cached,
- *              3 stream in / keep the output in the Infinity Cache, 4 state default-cached / side outputs streamed
- *   hundreds   streaming expansion (stickers + flags by few persistent waves): 1..7 -> 128, 192, 256, 384, 512, 768, 1024 waves, 8 -> off
- *   thousands  (2 digits) parts per walk group for expansion / ADI (1..A, rounded up to a divisor of A)
- *   100000s    dense one-hot writer: 1 -> 64-cube tiles, 2 -> 256-cube tiles (256-thread workgroups), 3 -> the wide form of
- *              rc_onehot_from_code (960-thread workgroups sweeping contiguous tile ranges; 3x3x3, superseded, kept for A/B; the
- *              thousands field then gives the wanted workgroup count / 16, the tens digit the sweep skew), 4 -> the front form of
- *              rc_onehot_from_code (one 3840-byte pass per workgroup; 3x3x3; the default from 2^15 / 2^16 / 2^18 cubes for f32 /
- *              16-bit / u8): units digit 1, 2, 4 = fronts per XCD per workgroup, tens digit 2 = one linear front, 3 = code bytes by
- *              a gather per lane, 4 = by one load of wave 0 + LDS.  Any non-zero value makes rc_apply_moves_ws ignore its workspace.
- *   millions   (2 digits) depth segments per walk group of the ADI kernel (1..16, clamped to depth) */
+/* ---------------------------------------------------------------------------------------------------------------------------------
+ * Tuning override (`variant`) of the *_ex entry points and of rc_describe_dispatch.  TOOLING: benchmarks and tests that must reach
+ * every kernel instantiation; there is NO process-global knob and a binding of the reference needs none of this (INTEGRATION.md lists
+ * the twelve entry points it does need).  Everything named *_ex, rc_describe_dispatch, rc_family_layout and rc_workspace_bytes is
+ * tooling in that sense.  0 = the measured defaults.  A value is the SUM of macros of ONE group below; an entry point rejects
+ * (RC_EINVAL) any decimal field its group does not define, so a value built for one entry point never means something else in another.
+ *
+ * rc_apply_moves_ex / RC_OP_STEP */
+#define RC_VARIANT_STEP_PACK(v) (v)                   /* 1, 2: 4, 8 cubes per lane */
+#define RC_VARIANT_STEP_POLICY(p) ((p) * 10)          /* row traffic: 1 stream in / stream out, 2 default-cached, 3 stream in / keep the
+                                                         output in the Infinity Cache, 4 state default-cached / side outputs streamed */
+#define RC_VARIANT_STEP_DENSE_TILE(t) ((t) * 100000)  /* fused dense writer: 1 -> 64-cube tiles, 2 -> 256-cube tiles; any non-zero value
+                                                         also makes rc_apply_moves_ws ignore its workspace */
+/* rc_expand_children_ex / RC_OP_EXPAND */
+#define RC_VARIANT_EXPAND_PACK(v) (v)                 /* 1, 2 */
+#define RC_VARIANT_EXPAND_STREAM(h) ((h) * 100)       /* streaming form (few persistent waves): 1..7 -> 128, 192, 256, 384, 512, 768, 1024
+                                                         waves, 8 -> never */
+#define RC_VARIANT_EXPAND_PARTS(p) ((p) * 1000)       /* 1..A parts per walk group (rounded up to a divisor of A) */
+/* rc_adi_generate_ex, rc_adi_generate_family / RC_OP_ADI */
+#define RC_VARIANT_ADI_PACK(v) (v)                    /* 1, 2 */
+#define RC_VARIANT_ADI_PARTS(p) ((p) * 1000)          /* 1..A */
+#define RC_VARIANT_ADI_SEGS(s) ((s) * 1000000)        /* 1..16 depth segments per walk group (clamped to the depth) */
+/* rc_onehot_from_code_ex / RC_OP_CODE_TO_DENSE */
+#define RC_VARIANT_DENSE_FORM(f) ((f) * 100000)       /* 1 -> 64-cube tiles, 2 -> 256-cube tiles, 3 -> the wide form (960-thread workgroups
+                                                         sweeping contiguous tile ranges; superseded, kept for A/B), 4 -> the front form (one
+                                                         3840-byte pass per workgroup; the default from 2^15 / 2^16 / 2^18 cubes, f32 / 16-bit / u8) */
+#define RC_VARIANT_DENSE_WIDE_GROUPS16(g) ((g) * 1000) /* form 3: wanted workgroups / 16 (1..99) */
+#define RC_VARIANT_DENSE_WIDE_SKEW(k) ((k) * 10)      /* form 3: sweep skew 1..9 */
+#define RC_VARIANT_DENSE_FRONTS(f) (f)                /* form 4 / default front: 1, 2, 4 fronts per XCD per workgroup */
+#define RC_VARIANT_DENSE_FRONT_FETCH(t) ((t) * 10)    /* form 4 / default front: 2 = one linear front, 3 = code bytes by a gather per lane,
+                                                         4 = by one load of wave 0 + LDS */
+/* rc_legacy_scramble_actions_ex (not decimal: mode + 16 * limit) */
+#define RC_VARIANT_LEGACY_LDS 1                       /* the LDS form alone */
+#define RC_VARIANT_LEGACY_STREAM(limit) (2 + 16 * (limit)) /* the streaming form with `limit` outputs per lane (1..227; 0 = 227) + fix-up */
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,9 @@ def _declare(L):
     L.rc_family_layout.argtypes = [i32, vp, vp]
     L.rc_onehot_from_family.argtypes = [vp, i64, i64, i32, vp, i32, i64, vp]
     L.rc_adi_targets.argtypes = [vp, vp, vp, vp, i64, i64, i32, vp, vp, vp, vp]
+    L.rc_adi_targets_depths.argtypes = [vp, i64, i64, vp, i64, vp, i64, vp, i64, i32, i32, vp, vp, vp, i64, vp]
+    L.rc_onehot_from_family_depths.argtypes = [vp, i64, i64, i32, vp, i32, i64, i32, vp]
+    L.rc_legacy_scramble_actions_ex.argtypes = [vp, vp, i32, i32, i64, i32, vp, i64, vp, i32]
     L.rc_read_status.argtypes = [vp, vp]
     L.rc_describe_dispatch.argtypes = [i32, i32, i64, i32, ctypes.c_uint32, i32, i32, ctypes.c_char_p, i32]
     L.rc_facade_release.argtypes = [vp]
@@ -65,7 +68,7 @@ def _declare(L):
                  "rc_legacy_scramble_actions", "rc_is_solved", "rc_encode", "rc_onehot_from_code", "rc_expand_children",
                  "rc_expand_children_ex", "rc_adi_generate", "rc_adi_generate_ex", "rc_adi_targets", "rc_read_status",
                  "rc_describe_dispatch", "rc_facade_release", "rc_onehot_from_code_ex", "rc_apply_moves_ws", "rc_encode_ws", "rc_adi_generate_family", "rc_family_layout",
-                 "rc_onehot_from_family"):
+                 "rc_onehot_from_family", "rc_adi_targets_depths", "rc_onehot_from_family_depths", "rc_legacy_scramble_actions_ex"):
         getattr(L, name).restype = i32
 
 

@@ -1,9 +1,17 @@
 """Batched ADI (autodidactic iteration) sample generation: SURVEY.md section 8 rows 14-15 and N1.
 
-Device work (librubikhip.so): the random walks and their 12-child expansion (rc_adi_generate_family: the
-51-byte family record per state; 2x2x2: rc_adi_generate with codes), the dense one-hots the value net reads
-(rc_onehot_from_family / rc_onehot_from_code) and the target assembly (rc_adi_targets).  The value net itself is the caller's unmodified torch module
-(model.py:31-45), called once per depth on 13 * walks states instead of twice per sample.
+Device work (librubikhip.so): the random walks and their 12-child expansion (rc_adi_generate_family: the 51-byte family record
+per state; 2x2x2: rc_adi_generate with codes), the dense one-hots the value net reads (rc_onehot_from_family_depths /
+rc_onehot_from_code) and the target assembly (rc_adi_targets_depths).  The value net itself is the caller's unmodified torch module
+(model.py:31-45).
+
+Shape of one call (AdiPlan): ONE generator launch per chunk of walks, then per GROUP of depths one launch that writes the
+[depths][A + 1][walks] one-hot input of the net, one forward of the net on that whole block and one launch that assembles the targets
+of every (walk, depth) of the group straight from the net's output into walk-major result tensors.  The blocks are packed (the block
+stride is the walk count rounded up to 8, not a padded tile count), and a group holds as many depths as the dense budget allows: the
+reference's own size, 200 walks x depth 30 (config/config.yaml:7-8, called every epoch by train.py:152-155), is one group -- one
+forward on 78 000 states instead of 30 forwards on 12 488 mostly padded rows.  `graph=True` captures everything behind the generator
+launch as a hipGraph over the plan's static buffers and replays it on later calls.
 
 Reference semantics kept (gym-cube/gym_cube/envs/cube_env.py:177-252):
   * sample (walk, d) = state after d moves, d = 1..depth, walks start from solved;
@@ -20,10 +28,10 @@ from . import _lib, ops
 from .tables import get_env_config
 
 
-@torch.no_grad()
-def adi_samples(model, cube_size, n_walks, depth, temperature, device="cuda", model_device=None, actions=None,
-                seed=0, stream_id=0, walk_offset=0, dense_budget_bytes=1 << 30, want_state_dense=False, dense_dtype=None):
-    """Generate n_walks x depth ADI samples.  Returns a dict of tensors on `device`, walk-major:
+class AdiPlan:
+    """Buffers and launch sequence of adi_samples for ONE shape (model, cube size, walks, depth, temperature, dtype).
+
+    run() returns a dict of tensors on `device`, walk-major:
 
         state_code     uint8   [W, D, SLOTS]   compact one-hot code of the sample state
         state          uint8   [W, D, R, C]    dense one-hot (only if want_state_dense)
@@ -33,73 +41,181 @@ def adi_samples(model, cube_size, n_walks, depth, temperature, device="cuda", mo
         error          float64 [W, D]
         actions        uint8   [W, D]          the move that led to the sample state
 
-    actions: optional uint8 [W, D] moves to replay (e.g. the host's legacy numpy draws, which makes
-    the samples those of the reference for the same global seed); None draws on the device.
-    dense_dtype: dtype of the one-hot stream fed to `model` (default: float32, or the dtype of the model's first floating-point
-    parameter when that is bfloat16 / float16); the returned values are float32 either way."""
-    dev = torch.device(device)
-    (R, C), A = get_env_config(cube_size)
-    SL = ops.N_SLOTS[cube_size]
-    mdev = torch.device(model_device) if model_device is not None else _module_device(model, dev)
-    # the dense stream is written in the dtype the net computes in (bf16 / f16 halve the 13 * p * 480 elements per depth)
-    ddtype = _module_dtype(model) if dense_dtype is None else dense_dtype
-    per_walk = (A + 1) * R * C * torch.empty((), dtype=ddtype).element_size()
-    chunk = max(1, min(n_walks, dense_budget_bytes // per_walk))
-    chunk = min(n_walks, max(1024, chunk // 1024 * 1024)) if n_walks > 1024 else n_walks
-    weights = [float(d) ** (-1 * temperature) for d in range(1, depth + 1)]  # cube_env.py:247, Python pow
-    outs = {k: [] for k in ("state_code", "target_value", "target_policy", "error", "actions")}
-    if want_state_dense:
-        outs["state"] = []
-    acts_all = None if actions is None else torch.as_tensor(actions, dtype=torch.uint8)
-    for w0 in range(0, n_walks, chunk):
-        wc = min(chunk, n_walks - w0)
-        # power-of-two pitch: the A children (and the `depth` parents) of a chunk are then ONE tiled code buffer
-        # of A * tiles (depth * tiles) tiles, so a single launch turns all of them into dense one-hots
-        # 3x3x3: the generator emits the FAMILY record (51 shared look-ups per state instead of 13 x 20 picked codes) and ONE
-        # rc_onehot_from_family launch per depth expands it to the 12 child blocks + the parent block; 2x2x2 keeps the codes
-        fam = cube_size == 3
-        pitch, bufs = ops.adi_buffers(wc, depth, cube_size, dev, pitch=1024 if wc <= 1024 else ops.ADI_TILE,
-                                      parent_code=not fam, child_code=not fam, family=fam)
-        p = bufs["actions_out"].shape[1]                      # padded walk count (tiles * pitch)
-        tiles = p // pitch
-        if fam:
-            prow = torch.from_numpy(_lib.family_layout(cube_size)[1][A].astype(np.int64)).to(dev)
-        a_in = None
-        if acts_all is not None:
-            a_host = torch.zeros((depth, p), dtype=torch.uint8)
-            a_host[:, :wc] = acts_all[w0:w0 + wc].t()
-            a_in = a_host.to(dev)
-        ops.adi_generate(wc, depth, cube_size, pitch, dev, seed=seed, stream_id=stream_id, walk_offset=walk_offset + w0,
-                         actions_in=a_in, **bufs)
-        dense = torch.zeros(((A + 1) * p, R, C), dtype=ddtype, device=dev)             # A child blocks + the parents (pad columns stay 0)
-        parent_code = bufs["family"].index_select(2, prow) if fam else bufs["parent_code"]   # [depth, tiles, SLOTS, pitch]
-        tv = torch.empty((depth, wc), dtype=torch.float32, device=dev)
-        tp = torch.empty((depth, wc), dtype=torch.int32, device=dev)
-        err = torch.empty((depth, wc), dtype=torch.float64, device=dev)
-        for d in range(depth):
-            if fam:
-                ops.onehot_from_family(bufs["family"][d], wc, cube_size, dense, block_stride=p)
+    These are the plan's OWN tensors, overwritten by the next run(): pass clone=True (adi_samples does) to keep them."""
+
+    def __init__(self, model, cube_size, n_walks, depth, temperature, device="cuda", model_device=None, dense_budget_bytes=1 << 30,
+                 want_state_dense=False, dense_dtype=None, graph=False):
+        self.model, self.cube_size, self.W, self.D = model, cube_size, int(n_walks), int(depth)
+        self.dev = dev = torch.device(device)
+        if dev.index is None and dev.type == "cuda":
+            self.dev = dev = torch.device("cuda", torch.cuda.current_device())
+        (self.R, self.C), self.A = get_env_config(cube_size)
+        self.SL = ops.N_SLOTS[cube_size]
+        self.mdev = torch.device(model_device) if model_device is not None else _module_device(model, dev)
+        if self.mdev.type == "cuda" and self.mdev.index is None:
+            self.mdev = torch.device("cuda", torch.cuda.current_device())
+        # the dense stream is written in the dtype the net computes in (bf16 / f16 halve the 13 * walks * 480 elements per depth)
+        self.ddtype = _module_dtype(model) if dense_dtype is None else dense_dtype
+        self.want_state_dense = bool(want_state_dense)
+        self.fam = cube_size == 3        # 3x3x3: the FAMILY record + one block-writing launch; 2x2x2 keeps parent / child codes
+        W, D, A = self.W, self.D, self.A
+        row_bytes = self.R * self.C * torch.empty((), dtype=self.ddtype).element_size()               # one dense one-hot
+        chunk = max(1, min(W, dense_budget_bytes // ((A + 1) * row_bytes)))                           # walks whose single depth fits the budget
+        self.chunk = min(W, max(1024, chunk // 1024 * 1024)) if W > 1024 else W
+        rows_of = lambda wc: self._geometry(wc)[2]
+        self.group = max(1, min(D, dense_budget_bytes // max(1, rows_of(self.chunk) * row_bytes)))   # depths per forward of the net
+        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+        self.out = {"state_code": e((W, D, self.SL), torch.uint8), "target_value": e((W, D), torch.float32),
+                    "target_policy": e((W, D), torch.int32), "error": e((W, D), torch.float64), "actions": e((W, D), torch.uint8),
+                    "scramble_count": torch.arange(1, D + 1, dtype=torch.int64, device=dev).expand(W, D).contiguous()}
+        if self.want_state_dense:
+            self.out["state"] = e((W, D, self.R, self.C), torch.uint8)
+        self.weights = torch.tensor([float(d) ** (-1 * temperature) for d in range(1, D + 1)], dtype=torch.float64, device=dev)  # cube_env.py:247, Python pow
+        if self.fam:
+            self.prow = torch.from_numpy(_lib.family_layout(cube_size)[1][A].astype(np.int64)).to(dev)
+        self.chunks = []                                           # (first walk, walks, device buffers, pinned staging of replayed moves)
+        by_size = {}                                               # chunks of one size share their device buffers (stream-ordered)
+        for w0 in range(0, W, self.chunk if W else 1):
+            wc = min(self.chunk, W - w0)
+            if wc not in by_size:
+                by_size[wc] = self._chunk_buffers(wc)
+            self.chunks.append((w0, wc, by_size[wc], [None]))
+        # zeros once: the pad rows between a block's walks and its stride are never written and must stay finite for the net
+        self.dense = torch.zeros((self.group * rows_of(self.chunk) if W and D else 0, self.R, self.C), dtype=self.ddtype, device=dev)
+        self.graph = bool(graph)
+        self._graphs = {}
+        if self.graph and self.mdev != dev:
+            raise ValueError("AdiPlan(graph=True) needs the model on the cubes' device (a host model cannot be captured)")
+
+    # ------------------------------------------------------------------ geometry
+    def _geometry(self, wc):
+        """(pitch of the generator's buffers, block stride, dense rows per depth) for a chunk of wc walks."""
+        if self.fam:                                               # blocks are addressed by a stride: pack them
+            pitch = _lib.pitch_for(wc) if wc <= ops.ADI_TILE else ops.ADI_TILE
+            bs = -(-wc // 8) * 8
+            return pitch, bs, (self.A + 1) * bs
+        # 2x2x2: a depth's A child buffers (and the parents of consecutive depths) are read as ONE tiled code buffer, which needs a
+        # power-of-two pitch >= 512; the block stride is then the padded walk count
+        pitch = max(ops.MIN_TILE, 1 << (wc - 1).bit_length()) if wc <= ops.ADI_TILE else ops.ADI_TILE
+        p = ops._tiles_of(wc, pitch) * pitch
+        return pitch, p, (self.A + 1) * p
+
+    def _chunk_buffers(self, wc):
+        pitch, bs, _ = self._geometry(wc)
+        pitch, bufs = ops.adi_buffers(wc, self.D, self.cube_size, self.dev, pitch=pitch, parent_code=not self.fam, child_code=not self.fam,
+                                      family=self.fam)
+        p = bufs["actions_out"].shape[1]                           # padded walk count (tiles * pitch)
+        b = {"pitch": pitch, "bs": bs, "p": p, "tiles": p // pitch, "bufs": bufs}
+        b["actions_in"] = torch.zeros((self.D, p), dtype=torch.uint8, device=self.dev)
+        return b
+
+    # ------------------------------------------------------------------ one chunk, behind the generator launch
+    def _after_generate(self, w0, wc, b):
+        A, D, SL, cs, dev = self.A, self.D, self.SL, self.cube_size, self.dev
+        bufs, bs, p, tiles, pitch = b["bufs"], b["bs"], b["p"], b["tiles"], b["pitch"]
+        tv, tp, err = (self.out[k][w0:] for k in ("target_value", "target_policy", "error"))
+        for g0 in range(0, D, self.group):
+            gc = min(self.group, D - g0)
+            rows = gc * (A + 1) * bs
+            x = self.dense[:rows]
+            if self.fam:
+                ops.onehot_from_family(bufs["family"][g0:g0 + gc], wc, cs, x, block_stride=bs, n_depths=gc)
             else:
-                ops.onehot_from_code(bufs["child_code"][d].view(A * tiles, SL, pitch), A * p, cube_size, dense[:A * p])
-                ops.onehot_from_code(bufs["parent_code"][d], wc, cube_size, dense[A * p:A * p + wc])
-            v = model(dense[:A * p + wc].to(mdev))[0].reshape(-1).to(device=dev, dtype=torch.float32)
-            child_value = v[:A * p].view(A, p)                   # exactly rc_adi_targets' [A][pitch] layout
-            pv = v[A * p:].contiguous()
-            w = torch.full((wc,), weights[d], dtype=torch.float64, device=dev)
-            tv[d], tp[d], err[d] = ops.adi_targets(child_value.contiguous(), bufs["child_solved"][d], wc, cube_size, pv, w)
-        outs["state_code"].append(torch.stack([ops.to_aos(parent_code[d], wc) for d in range(depth)], 1).contiguous())
-        outs["actions"].append(bufs["actions_out"][:, :wc].t().contiguous())
-        outs["target_value"].append(tv.t().contiguous())
-        outs["target_policy"].append(tp.t().contiguous())
-        outs["error"].append(err.t().contiguous())
-        if want_state_dense:
-            sd = torch.empty((depth * p, R, C), dtype=torch.uint8, device=dev)
-            ops.onehot_from_code(parent_code.reshape(depth * tiles, SL, pitch), depth * p, cube_size, sd)
-            outs["state"].append(sd.view(depth, p, R, C)[:, :wc].permute(1, 0, 2, 3).contiguous())
-    _lib_status(dev)
-    res = {k: torch.cat(v, 0) for k, v in outs.items()}
-    res["scramble_count"] = torch.arange(1, depth + 1, dtype=torch.int64, device=dev).expand(n_walks, depth).contiguous()
-    return res
+                ops.onehot_from_code(bufs["child_code"][g0:g0 + gc].view(gc * A * tiles, SL, pitch), gc * A * p, cs, x[:gc * A * p])
+                ops.onehot_from_code(bufs["parent_code"][g0:g0 + gc].view(gc * tiles, SL, pitch), gc * p, cs, x[gc * A * p:])
+            v = self.model(x if self.mdev == dev else x.to(self.mdev))[0].reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+            if self.fam:                                           # [depth][A children, parent][bs]
+                cv, cvd, pv, pvd = v, (A + 1) * bs, v[A * bs:], (A + 1) * bs
+            else:                                                  # [depth][A][p] children, then [depth][p] parents
+                cv, cvd, pv, pvd = v, A * p, v[gc * A * p:], p
+            ops.adi_targets_depths(cv, cvd, bs, bufs["child_solved"][g0:g0 + gc], pv, pvd, self.weights[g0:g0 + gc], wc, gc, cs,
+                                   tv[:, g0:], tp[:, g0:], err[:, g0:])
+        # walk-major copies of the generator's rows: parent codes (the sample states) and the moves
+        pc = bufs["family"].index_select(2, self.prow) if self.fam else bufs["parent_code"]          # [D, tiles, SL, pitch]
+        src = pc.permute(1, 3, 0, 2)                                                                 # [tiles, pitch, D, SL]
+        sc = self.out["state_code"]
+        full = wc // pitch
+        if full:
+            sc[w0:w0 + full * pitch].view(full, pitch, D, SL).copy_(src[:full])
+        if wc > full * pitch:
+            sc[w0 + full * pitch:w0 + wc].copy_(src[full, :wc - full * pitch])
+        self.out["actions"][w0:w0 + wc].copy_(bufs["actions_out"][:, :wc].t())
+        if self.want_state_dense:
+            sd = torch.empty((D * p, self.R, self.C), dtype=torch.uint8, device=dev)
+            ops.onehot_from_code(pc.reshape(D * tiles, SL, pitch), D * p, cs, sd)
+            self.out["state"][w0:w0 + wc].copy_(sd.view(D, p, self.R, self.C)[:, :wc].permute(1, 0, 2, 3))
+
+    @torch.no_grad()
+    def run(self, actions=None, seed=0, stream_id=0, walk_offset=0, clone=False):
+        """actions: optional uint8 [W, D] moves to replay (e.g. the host's legacy numpy draws, which makes the samples those of the
+        reference for the same global seed); None draws on the device from (seed, stream_id, walk_offset + walk)."""
+        dev = self.dev
+        acts_all = None
+        if actions is not None:
+            acts_all = torch.as_tensor(actions, dtype=torch.uint8)
+            if tuple(acts_all.shape) != (self.W, self.D):
+                raise ValueError(f"actions must be [{self.W}, {self.D}]")
+        for w0, wc, b, stage in self.chunks if self.D else ():
+            a_in = None
+            if acts_all is not None:
+                if acts_all.is_cuda:
+                    b["actions_in"][:, :wc].copy_(acts_all[w0:w0 + wc].t())
+                else:                                              # the chunk's own pinned staging buffer (the last run ended with a
+                    if stage[0] is None:                           # synchronisation, so it is free), one asynchronous upload
+                        stage[0] = torch.zeros((self.D, b["p"]), dtype=torch.uint8).pin_memory()
+                    stage[0][:, :wc].copy_(acts_all[w0:w0 + wc].t())
+                    b["actions_in"].copy_(stage[0], non_blocking=True)
+                a_in = b["actions_in"]
+            ops.adi_generate(wc, self.D, self.cube_size, b["pitch"], dev, seed=seed, stream_id=stream_id, walk_offset=walk_offset + w0,
+                             actions_in=a_in, **b["bufs"])
+            if not self.graph:
+                self._after_generate(w0, wc, b)
+                continue
+            g = self._graphs.get(w0)
+            if g is None:                                          # warm-up on a side stream, then capture (as rollout.py does)
+                s = torch.cuda.Stream(dev)
+                s.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(s):
+                    self._after_generate(w0, wc, b)
+                torch.cuda.current_stream(dev).wait_stream(s)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._after_generate(w0, wc, b)
+                self._graphs[w0] = g
+            g.replay()
+        _lib_status(dev)
+        return {k: (v.clone() if clone else v) for k, v in self.out.items()}
+
+
+_plans = {}          # adi_samples(graph=True): captured plans per call shape, so that repeated calls replay instead of re-capturing
+
+
+def adi_samples(model, cube_size, n_walks, depth, temperature, device="cuda", model_device=None, actions=None,
+                seed=0, stream_id=0, walk_offset=0, dense_budget_bytes=1 << 30, want_state_dense=False, dense_dtype=None, graph=False):
+    """Generate n_walks x depth ADI samples (see AdiPlan for the result dict, the semantics and the launch sequence).
+
+    actions: optional uint8 [W, D] moves to replay; None draws on the device.
+    dense_dtype: dtype of the one-hot stream fed to `model` (default: float32, or the dtype of the model's first floating-point
+    parameter when that is bfloat16 / float16); the returned values are float32 either way.
+    graph: keep the plan of this call shape (static buffers + the captured hipGraph of everything behind the generator launch) in a
+    module-level cache and replay it on the next call with the same model object and shape; results are copies either way."""
+    if not graph:
+        return AdiPlan(model, cube_size, n_walks, depth, temperature, device, model_device, dense_budget_bytes, want_state_dense,
+                       dense_dtype).run(actions, seed, stream_id, walk_offset)
+    key = (id(model), cube_size, int(n_walks), int(depth), float(temperature), str(torch.device(device)), str(model_device), int(dense_budget_bytes),
+           bool(want_state_dense), str(dense_dtype))
+    plan = _plans.get(key)
+    if plan is None or plan.model is not model:
+        if len(_plans) >= 8:
+            _plans.pop(next(iter(_plans)))
+        plan = _plans[key] = AdiPlan(model, cube_size, n_walks, depth, temperature, device, model_device, dense_budget_bytes, want_state_dense,
+                                     dense_dtype, graph=True)
+    return plan.run(actions, seed, stream_id, walk_offset, clone=True)
+
+
+def release_plans():
+    """Drop the plans adi_samples(graph=True) keeps (their device buffers and captured graphs)."""
+    _plans.clear()
 
 
 def _lib_status(dev):

@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <mutex>
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -339,11 +341,14 @@ __global__ void __launch_bounds__(kWideBlock) k_code_to_dense_wide(const uint8_t
 // (Wave-uniform scalar loads of the rows + a select chain were tried and lost: 0.64 against 0.81, bf16.)
 // FAM: `code` holds FAMILY rows ([tile][NF][pitch], rc_device.h FamilyLayout) and the launch writes A + 1 blocks -- child a's one-hots
 // at dense + a * block_stride cubes, the parent's as block A: global pass = block * passes_per_block + pass; slot r of block a is family
-// row kFamily.row[a][r] (the per-child pick, from a 260-byte table in constant memory).
+// row kFamily.row[a][r] (the per-child pick, from a 260-byte table in constant memory).  Several DEPTHS of one ADI launch go in one
+// launch too (fam.nblk = (A + 1) * depths blocks): depth g reads its family record at code + g * fam.src_depth_stride bytes and writes its
+// A + 1 blocks at dense + g * fam.dst_depth_stride cubes, so the whole [depth][A + 1][block_stride] model input of a small batch is one launch.
 __constant__ FamilyLayout<Cube3> c_family3{};
+struct FamilyBlocks { int64_t block_stride, ppb, src_depth_stride, dst_depth_stride; int nblk; };
 template <class T, class E, int F, bool LDS, bool FAM = false>
 __global__ void __launch_bounds__(256) k_code_to_dense_front(const uint8_t *__restrict__ code, int64_t n, int64_t code_pitch, int shift, E *__restrict__ dense,
-                                                             int64_t per_xcd, int64_t per_front, int64_t block_stride = 0, int64_t ppb = 0) {
+                                                             int64_t per_xcd, int64_t per_front, FamilyBlocks fam = {}) {
     static_assert(T::SIZE == 3);
     constexpr int ROWS = FAM ? kFamily<T>.nf : T::SLOTS;                         // rows of one tile of the input
     constexpr int EPT = 16 / (int)sizeof(E), CPC = 480 / EPT, CPP = 240 / CPC;   // elements per chunk, chunks per cube, cubes per pass
@@ -362,14 +367,18 @@ __global__ void __launch_bounds__(256) k_code_to_dense_front(const uint8_t *__re
     uint32_t ca[F], cb[F];
     bool live[F];
     // FAM: which block (child / parent) a global pass belongs to, its pass inside the block, and the input row of slot r there
-    int blk[F];
-    int64_t lpass[F];
+    int blk[F];                                                                  // child (A = the parent) inside its depth
+    int64_t lpass[F], src_off[F], dst_cube[F];                                   // pass inside the block; byte offset of the depth's record; first cube of the block
 #pragma unroll
     for (int f = 0; f < F; ++f) {
         const int64_t gp = pass0 + f * per_front;
-        blk[f] = FAM ? (int)(gp / ppb) : 0;
-        lpass[f] = FAM ? gp - (int64_t)blk[f] * ppb : gp;
-        if (FAM && blk[f] > T::A) { blk[f] = T::A; lpass[f] = ppb; }               // beyond the last block: lpass * CPP >= n, nothing live
+        int b = FAM ? (int)(gp / fam.ppb) : 0;
+        lpass[f] = FAM ? gp - (int64_t)b * fam.ppb : gp;
+        if (FAM && b >= fam.nblk) { b = fam.nblk - 1; lpass[f] = fam.ppb; }       // beyond the last block: lpass * CPP >= n, nothing live
+        const int g = FAM ? b / (T::A + 1) : 0;
+        blk[f] = b - g * (T::A + 1);
+        src_off[f] = FAM ? (int64_t)g * fam.src_depth_stride : 0;
+        dst_cube[f] = FAM ? (int64_t)g * fam.dst_depth_stride + (int64_t)blk[f] * fam.block_stride : 0;
     }
     auto in_row = [&](int f, int r) { return FAM ? (int)c_family3.row[blk[f]][r] : r; };
     if constexpr (LDS) {
@@ -378,7 +387,7 @@ __global__ void __launch_bounds__(256) k_code_to_dense_front(const uint8_t *__re
             const int64_t cube0 = lpass[f] * CPP, a0 = cube0 & ~(int64_t)3;
             if (tid < T::SLOTS * WORDS && cube0 < n && (f == 0 || per_front > 0)) {
                 const int r = tid / WORDS, w = tid - r * WORDS;
-                rows[f][tid] = *reinterpret_cast<const uint32_t *>(code + tile_off(a0 + 4 * w, code_pitch, shift, ROWS) + (int64_t)in_row(f, r) * code_pitch);
+                rows[f][tid] = *reinterpret_cast<const uint32_t *>(code + src_off[f] + tile_off(a0 + 4 * w, code_pitch, shift, ROWS) + (int64_t)in_row(f, r) * code_pitch);
             }
         }
         __syncthreads();
@@ -394,7 +403,7 @@ __global__ void __launch_bounds__(256) k_code_to_dense_front(const uint8_t *__re
                 ca[f] = (rows[f][ra * WORDS + (byte >> 2)] >> (8 * (byte & 3))) & 0xffu;
                 if constexpr (sizeof(E) == 1) cb[f] = (rows[f][rb * WORDS + (byte >> 2)] >> (8 * (byte & 3))) & 0xffu;
             } else {
-                const uint8_t *src = code + tile_off(cube, code_pitch, shift, ROWS);       // row 0 of this cube's column
+                const uint8_t *src = code + src_off[f] + tile_off(cube, code_pitch, shift, ROWS);   // row 0 of this cube's column
                 ca[f] = src[(int64_t)in_row(f, ra) * code_pitch];
                 if constexpr (sizeof(E) == 1) cb[f] = src[(int64_t)in_row(f, rb) * code_pitch];
             }
@@ -415,7 +424,7 @@ __global__ void __launch_bounds__(256) k_code_to_dense_front(const uint8_t *__re
             }
         }
         // the pass is 3840 contiguous bytes: thread t owns bytes 16 t ..
-        bst<4, RC_DENSE_AUX>(make_srd(dense + ((int64_t)blk[f] * block_stride + lpass[f] * CPP) * 480), (uint32_t)tid * 16u, 0, u);
+        bst<4, RC_DENSE_AUX>(make_srd(dense + (dst_cube[f] + lpass[f] * CPP) * 480), (uint32_t)tid * 16u, 0, u);
     }
 }
 
@@ -760,66 +769,144 @@ __global__ void __launch_bounds__(kWave) k_scramble(ScrambleArgs a) {
 // conflict-free).  All lanes consume one output per iteration, so the state index -- and with it the
 // twist -- stays wave-uniform; lanes only differ in how many outputs they accept.
 constexpr int kMtN = 624, kMtM = 397;
+constexpr uint8_t kLegacyRedo = 0xff;                          // row-0 sentinel of a lane the streaming kernel could not finish
 
+__device__ __forceinline__ uint32_t mt_next_seed(uint32_t x, uint32_t i) { return 1812433253u * (x ^ (x >> 30)) + i; }   // init_genrand
+__device__ __forceinline__ uint32_t mt_twist(uint32_t cur, uint32_t nxt, uint32_t far) {
+    const uint32_t y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
+    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+}
+
+// The general form: the whole generator in LDS.  The twist is LAZY -- word k of a generation only needs words k, k + 1 and k + 397 of the
+// previous one (k < 227) or word k - 227 of its own, so twisting in blocks of 64 right before they are consumed is the in-place
+// algorithm in the same order; a reset(seed, 30) consumes ~45 outputs = one block instead of all 624 words.
+// fixup != 0: the launch follows k_legacy_actions_stream and redoes only the waves in which a lane left the kLegacyRedo sentinel in
+// row 0 (a grid-stride scan, 256 envs per load).
 template <int A_>
 __global__ void __launch_bounds__(kWave) k_legacy_actions(const uint32_t *seeds, const int32_t *counts, int count_uniform, int kmax,
-                                                          int64_t n, uint8_t *actions_out, int64_t pitch) {
+                                                          int64_t n, uint8_t *actions_out, int64_t pitch, int fixup) {
     __shared__ uint32_t mt[kMtN * kWave];
     const int lane = threadIdx.x;
-    const int64_t env = (int64_t)blockIdx.x * kWave + lane;
+    const int64_t n_waves = (n + kWave - 1) / kWave;
+    const int64_t step = fixup ? 4 : 1;                        // wave ids per iteration of the outer loop
+    for (int64_t w0 = (int64_t)blockIdx.x * step; w0 < n_waves; w0 += (int64_t)gridDim.x * step) {
+        uint64_t redo = ~0ull;
+        if (fixup) {                                           // one dword per lane = row 0 of 256 envs
+            const int64_t e4 = w0 * kWave + 4 * lane;
+            uint32_t word = e4 < n ? *reinterpret_cast<const uint32_t *>(actions_out + e4) : 0u;
+            bool hit = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hit |= e4 + j < n && ((word >> (8 * j)) & 0xffu) == kLegacyRedo;
+            redo = __ballot(hit);
+            if (redo == 0) continue;
+        }
+        for (int64_t w = w0; w < w0 + step && w < n_waves; ++w) {
+            if (fixup && ((redo >> (16 * (w - w0))) & 0xffffull) == 0) continue;
+            const int64_t env = w * kWave + lane;
+            const bool live = env < n;
+            int want = live ? (counts ? counts[env] : count_uniform) : 0;
+            want = want < 0 ? 0 : want > kmax ? kmax : want;   // counts live in device memory: never write past [kmax][pitch]
+            uint32_t x = live ? seeds[env] : 0u;               // init_genrand
+            mt[lane] = x;
+            for (int i = 1; i < kMtN; ++i) {
+                x = mt_next_seed(x, (uint32_t)i);
+                mt[i * kWave + lane] = x;
+            }
+            constexpr uint32_t rng = A_ - 1;
+            constexpr uint32_t mask = rng | rng >> 1 | rng >> 2 | rng >> 3;   // 15 for 12 actions, 7 for 6
+            int idx = kMtN, twisted = kMtN, got = 0;           // numpy seeds with mti = 624: the first draw starts a generation
+            while (__any(got < want)) {
+                if (idx == kMtN) { idx = 0; twisted = 0; }     // new generation: nothing of it is twisted yet
+                if (idx == twisted) {                          // genrand's in-place twist, the next block of (up to) 64 words
+                    const int hi = twisted + 64 < kMtN ? twisted + 64 : kMtN;
+                    for (int k = twisted; k < hi; ++k) {
+                        const int k1 = k + 1 == kMtN ? 0 : k + 1, km = k + kMtM >= kMtN ? k + kMtM - kMtN : k + kMtM;
+                        mt[k * kWave + lane] = mt_twist(mt[k * kWave + lane], mt[k1 * kWave + lane], mt[km * kWave + lane]);
+                    }
+                    twisted = hi;
+                }
+                const uint32_t v = mt_temper(mt[idx * kWave + lane]) & mask;
+                ++idx;
+                if (got < want && v <= rng) {                  // masked rejection (numpy _bounded_integers, legacy path)
+                    actions_out[(int64_t)got * pitch + env] = (uint8_t)v;
+                    ++got;
+                }
+            }
+            if (live)
+                for (int d = want; d < kmax; ++d) actions_out[(int64_t)d * pitch + env] = (uint8_t)A_;   // pad with the no-op
+        }
+    }
+}
+
+// The common case -- reset(seed, k) with a few dozen moves -- needs no state at all.  Outputs 0..226 of the first generation are
+//   temper(x[k + 397] ^ twist(x[k], x[k + 1]))     with x = the init_genrand chain of the seed,
+// so two chain iterators (one at k, one 397 words ahead) produce them in registers: no LDS, full occupancy, ~25 VALU instructions per
+// output after a 397-step prelude.  A lane that still wants draws after `limit` (<= 227) outputs leaves kLegacyRedo in row 0 and the
+// wave is redone by the LDS kernel above (launched right behind this one in fixup mode): exact for every seed and count.
+template <int A_>
+__global__ void __launch_bounds__(256) k_legacy_actions_stream(const uint32_t *seeds, const int32_t *counts, int count_uniform, int kmax,
+                                                               int64_t n, uint8_t *actions_out, int64_t pitch, int limit) {
+    const int64_t env = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = env < n;
     int want = live ? (counts ? counts[env] : count_uniform) : 0;
-    want = want < 0 ? 0 : want > kmax ? kmax : want;           // counts live in device memory: never write past [kmax][pitch]
-    uint32_t x = live ? seeds[env] : 0u;                       // init_genrand
-    mt[lane] = x;
-    for (int i = 1; i < kMtN; ++i) {
-        x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i;
-        mt[i * kWave + lane] = x;
-    }
+    want = want < 0 ? 0 : want > kmax ? kmax : want;
+    uint32_t xa = live ? seeds[env] : 0u, xb = xa;
+    for (uint32_t i = 1; i <= (uint32_t)kMtM; ++i) xb = mt_next_seed(xb, i);        // xb = x[397]
     constexpr uint32_t rng = A_ - 1;
-    constexpr uint32_t mask = rng | rng >> 1 | rng >> 2 | rng >> 3;   // 15 for 12 actions, 7 for 6
-    int idx = kMtN, got = 0;                                   // numpy seeds with mti = 624: the first draw twists
-    while (__any(got < want)) {
-        if (idx == kMtN) {                                     // genrand's in-place twist of the whole state
-            for (int k = 0; k < kMtN; ++k) {
-                const int k1 = k + 1 == kMtN ? 0 : k + 1, km = k + kMtM >= kMtN ? k + kMtM - kMtN : k + kMtM;
-                const uint32_t y = (mt[k * kWave + lane] & 0x80000000u) | (mt[k1 * kWave + lane] & 0x7fffffffu);
-                mt[k * kWave + lane] = mt[km * kWave + lane] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-            }
-            idx = 0;
-        }
-        uint32_t y = mt[idx * kWave + lane];
-        ++idx;
-        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
-        const uint32_t v = y & mask;
-        if (got < want && v <= rng) {                          // masked rejection (numpy _bounded_integers, legacy path)
+    constexpr uint32_t mask = rng | rng >> 1 | rng >> 2 | rng >> 3;
+    int got = 0;
+    for (int k = 0; k < limit && __any(got < want); ++k) {
+        const uint32_t xa1 = mt_next_seed(xa, (uint32_t)k + 1u);
+        const uint32_t v = mt_temper(mt_twist(xa, xa1, xb)) & mask;
+        xa = xa1;
+        xb = mt_next_seed(xb, (uint32_t)(k + kMtM) + 1u);                            // (the word past x[623] is never used: limit <= 227)
+        if (got < want && v <= rng) {
             actions_out[(int64_t)got * pitch + env] = (uint8_t)v;
             ++got;
         }
     }
-    if (live)
-        for (int d = want; d < kmax; ++d) actions_out[(int64_t)d * pitch + env] = (uint8_t)A_;   // pad with the no-op
+    if (!live) return;
+    if (got < want) { actions_out[env] = kLegacyRedo; return; }
+    for (int d = want; d < kmax; ++d) actions_out[(int64_t)d * pitch + env] = (uint8_t)A_;
 }
 
 // ------------------------------------------------------------------------ ADI targets
+// One thread per (walk, depth).  Inputs are addressed by strides so that the SAME kernel serves one depth (rc_adi_targets: child_value
+// [A][pitch]) and a whole group of depths straight out of the value net's output (rc_adi_targets_depths: value [G][A + 1][block_stride],
+// child_solved [G][A][Wp], one weight per depth); results land walk-major, out[w * out_stride + g], the layout the replay sink keeps.
+struct TargetArgs {
+    const float *child_value;  int64_t cv_depth, cv_child;     // child_value[g * cv_depth + a * cv_child + w]
+    const uint8_t *child_solved; int64_t cs_depth, cs_child;
+    const float *parent_value; int64_t pv_depth;                // parent_value[g * pv_depth + w]
+    const double *weight;      int weight_per_depth;            // weight[g] (one per depth) or weight[w] (one per walk, G == 1)
+    int64_t n;
+    float *target_value; int32_t *target_policy; double *error;
+    int64_t out_stride;                                         // elements between two walks of an output array
+};
 template <int A_>
-__global__ void __launch_bounds__(256) k_adi_targets(const float *child_value, const uint8_t *child_solved, const float *parent_value,
-                                                     const double *weight, int64_t n, int64_t pitch,
-                                                     float *target_value, int32_t *target_policy, double *error) {
+__global__ void __launch_bounds__(256) k_adi_targets(TargetArgs t) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    const int64_t g = blockIdx.y;
+    if (i >= t.n) return;
+    const float *cv = t.child_value + g * t.cv_depth + i;
+    const uint8_t *cs = t.child_solved + g * t.cs_depth + i;
     float best = 0.f;
     int arg = -1, solved_at = -1;
 #pragma unroll
     for (int k = 0; k < A_; ++k) {
-        const float v = child_value[k * pitch + i] + (-1.0f);       // cube_env.py:244  value + reward
-        if (child_solved[k * pitch + i] && solved_at < 0) solved_at = k;  // cube_env.py:229-232  first solved child wins
-        if (arg < 0 || v > best) { best = v; arg = k; }               // torch.max: first maximal index
+        const float v = cv[k * t.cv_child] + (-1.0f);                    // cube_env.py:244  value + reward
+        if (cs[k * t.cs_child] && solved_at < 0) solved_at = k;          // cube_env.py:229-232  first solved child wins
+        if (arg < 0 || v > best) { best = v; arg = k; }                  // torch.max: first maximal index
     }
     const float tv = solved_at >= 0 ? 1.0f : best;
-    target_value[i] = tv;
-    target_policy[i] = solved_at >= 0 ? solved_at : arg;
-    if (error) error[i] = fabs((double)parent_value[i] - (double)tv) * weight[i];  // cube_env.py:247-251
+    const int64_t o = i * t.out_stride + g;
+    t.target_value[o] = tv;
+    t.target_policy[o] = solved_at >= 0 ? solved_at : arg;
+    if (t.error) t.error[o] = fabs((double)t.parent_value[g * t.pv_depth + i] - (double)tv) * t.weight[t.weight_per_depth ? g : i];  // cube_env.py:247-251
 }
 
 // ------------------------------------------------------- batch-1 facade step (latency path)
@@ -1057,6 +1144,25 @@ int by_size(int cube_size, F &&f) {
 // policy follows the working set (RowPolicy).
 // Round-3 sweep over 2^18 .. 2^24 cubes x {done, reward, code, in place} (profiles/r03_ab.json): with every side store a
 // contiguous 1-KiB instruction V = 2 wins or ties everywhere from 2^18 cubes up (V = 1 is 2 % ahead only around 2^21).
+// Which decimal fields of `variant` an entry point defines (include/rubikhip.h RC_VARIANT_*): anything else is RC_EINVAL, in the
+// *_ex launchers and in rc_describe_dispatch alike, so a value composed for one entry point cannot silently mean something else in another.
+int check_variant(int op, int A, int variant) {
+    if (variant == 0) return RC_OK;
+    const int units = variant % 10, tens = (variant / 10) % 10, hundreds = (variant / 100) % 10, field = (variant / 1000) % 100,
+              form = (variant / 100000) % 10, segs = (variant / 1000000) % 100, rest = variant / 100000000;
+    bool ok = variant > 0 && rest == 0;
+    if (op == RC_OP_STEP) ok = ok && units <= 2 && tens <= 4 && hundreds == 0 && field == 0 && form <= 2 && segs == 0;
+    else if (op == RC_OP_EXPAND) ok = ok && units <= 2 && tens == 0 && hundreds <= 8 && field <= A && form == 0 && segs == 0;
+    else if (op == RC_OP_ADI) ok = ok && units <= 2 && tens == 0 && hundreds == 0 && field <= A && form == 0 && segs <= 16;
+    else if (op == RC_OP_CODE_TO_DENSE) {
+        ok = ok && hundreds == 0 && segs == 0 && form <= 4;
+        if (form == 3) ok = ok && units == 0;                                               // wide: tens = skew, field = groups / 16
+        else if (form == 0 || form == 4) ok = ok && (units <= 2 || units == 4) && (tens == 0 || (tens >= 2 && tens <= 4)) && field == 0;   // front
+        else ok = ok && units == 0 && tens == 0 && field == 0;
+    } else ok = false;
+    return ok ? RC_OK : fail(RC_EINVAL, "variant: a field this entry point does not define is set (include/rubikhip.h RC_VARIANT_*)%s");
+}
+
 int pick_v(int64_t n, int variant) {
     const int v = variant % 10;
     if (v == 1 || v == 2) return v;
@@ -1233,22 +1339,24 @@ int launch_front_shape(const uint8_t *code, int64_t n, int64_t code_pitch, int s
 }
 // family rows -> the dense one-hots of all A children and the parent (block a at onehot + a * block_stride cubes): the front writer
 // over (A + 1) * ceil(n / cubes per pass) passes, same shapes per format as the code -> dense launch
+struct FamilyDepths { int n_depths; int64_t src_depth_stride, dst_depth_stride; };   // strides: bytes of one depth's record / cubes of one depth's blocks
 template <class T, class E, int F, bool LDS>
-int launch_family_e(const uint8_t *fam, int64_t n, int64_t pitch, int sh, E *onehot, int64_t block_stride, hipStream_t st) {
+int launch_family_e(const uint8_t *fam, int64_t n, int64_t pitch, int sh, E *onehot, int64_t block_stride, FamilyDepths dp, hipStream_t st) {
     constexpr int cpp = 240 / (480 / (16 / (int)sizeof(E)));
-    const int64_t ppb = (n + cpp - 1) / cpp, passes = ppb * (T::A + 1);
+    const int64_t ppb = (n + cpp - 1) / cpp, passes = ppb * (T::A + 1) * dp.n_depths;
     const int64_t per_front = (passes + 8 * F - 1) / (8 * F), per_xcd = per_front * F, blocks = per_front * 8;
     RC_GRID(blocks);
-    hipLaunchKernelGGL((k_code_to_dense_front<T, E, F, LDS, true>), dim3((unsigned)blocks), dim3(256), 0, st, fam, n, pitch, sh, onehot, per_xcd, per_front, block_stride, ppb);
+    const FamilyBlocks fb{block_stride, ppb, dp.src_depth_stride, dp.dst_depth_stride, (T::A + 1) * dp.n_depths};
+    hipLaunchKernelGGL((k_code_to_dense_front<T, E, F, LDS, true>), dim3((unsigned)blocks), dim3(256), 0, st, fam, n, pitch, sh, onehot, per_xcd, per_front, fb);
     RC_HIP(hipGetLastError());
     return RC_OK;
 }
 template <class T>
-int launch_family_to_dense(const uint8_t *fam, int64_t n, int64_t pitch, int sh, void *onehot, int fmt, int64_t block_stride, hipStream_t st) {
-    if (fmt == RC_FMT_U8) return launch_family_e<T, uint8_t, 2, true>(fam, n, pitch, sh, static_cast<uint8_t *>(onehot), block_stride, st);
-    if (fmt == RC_FMT_F16) return launch_family_e<T, uint16_t, 1, true>(fam, n, pitch, sh, static_cast<uint16_t *>(onehot), block_stride, st);
-    if (fmt == RC_FMT_BF16) return launch_family_e<T, Bf16, 1, true>(fam, n, pitch, sh, static_cast<Bf16 *>(onehot), block_stride, st);
-    return launch_family_e<T, float, 1, false>(fam, n, pitch, sh, static_cast<float *>(onehot), block_stride, st);
+int launch_family_to_dense(const uint8_t *fam, int64_t n, int64_t pitch, int sh, void *onehot, int fmt, int64_t block_stride, FamilyDepths dp, hipStream_t st) {
+    if (fmt == RC_FMT_U8) return launch_family_e<T, uint8_t, 2, true>(fam, n, pitch, sh, static_cast<uint8_t *>(onehot), block_stride, dp, st);
+    if (fmt == RC_FMT_F16) return launch_family_e<T, uint16_t, 1, true>(fam, n, pitch, sh, static_cast<uint16_t *>(onehot), block_stride, dp, st);
+    if (fmt == RC_FMT_BF16) return launch_family_e<T, Bf16, 1, true>(fam, n, pitch, sh, static_cast<Bf16 *>(onehot), block_stride, dp, st);
+    return launch_family_e<T, float, 1, false>(fam, n, pitch, sh, static_cast<float *>(onehot), block_stride, dp, st);
 }
 
 template <class T>
@@ -1410,7 +1518,7 @@ int launch_adi(AdiArgs a, hipStream_t st) {
 // =============================================================================== C ABI
 extern "C" {
 
-int rc_version(void) { return 400; }
+int rc_version(void) { return 500; }
 
 const char *rc_last_error(void) { return t_err; }
 
@@ -1477,6 +1585,7 @@ static int step_common(const uint8_t *in, uint8_t *out, const uint8_t *actions, 
                        int cube_size, float *reward, uint8_t *done, void *onehot, int fmt, int64_t code_pitch, void *stream,
                        bool move, bool store, int variant, void *workspace = nullptr, int64_t workspace_bytes = 0) {
     RC_NEED_INIT();
+    if (int rc = check_variant(RC_OP_STEP, 12, variant)) return rc;
     const int sh_in = tile_shift(pitch_in, n), sh_out = store ? tile_shift(pitch_out, n) : 63;
     int sh_code = 63;
     if (!in || !aligned16(in) || n < 0 || sh_in < 0) return fail(RC_EINVAL, "bad input state buffer / pitch%s");
@@ -1494,6 +1603,17 @@ static int step_common(const uint8_t *in, uint8_t *out, const uint8_t *actions, 
             if constexpr (T::SIZE == 3) {
                 const int64_t need = dense_workspace_bytes(3, n, fmt);
                 if (workspace && need > 0 && workspace_bytes >= need && (variant / 100000) % 10 == 0) {
+                    // the workspace is written by the first launch and read by the second while `onehot` is being written: it must not
+                    // share a byte with any operand (a caller carving it out of the one-hot allocation would get silently wrong rows)
+                    const auto hits = [&](const void *p, int64_t bytes) {
+                        const uintptr_t w0 = reinterpret_cast<uintptr_t>(workspace), p0 = reinterpret_cast<uintptr_t>(p);
+                        return p != nullptr && bytes > 0 && p0 < w0 + (uintptr_t)need && w0 < p0 + (uintptr_t)bytes;
+                    };
+                    const auto state_bytes = [&](int64_t pitch) { return (n <= pitch ? 1 : (n + pitch - 1) / pitch) * T::S * pitch; };
+                    const int64_t esize = fmt == RC_FMT_U8 ? 1 : fmt == RC_FMT_F32 ? 4 : 2;
+                    if (hits(in, state_bytes(pitch_in)) || (store && hits(out, state_bytes(pitch_out))) || hits(actions, n) || hits(reward, 4 * n) ||
+                        hits(done, n) || hits(onehot, n * T::R * T::C * esize))
+                        return fail(RC_EINVAL, "workspace overlaps an input or output buffer%s");
                     // step (or encode) + reward + done + compact code (into the workspace), then the front writer: the dense stream
                     // leaves as one sweeping window instead of thousands of private 240-KiB streams (k_code_to_dense_front)
                     StepArgs a2 = a;
@@ -1561,20 +1681,43 @@ int rc_scramble(uint8_t *stp, int64_t n, int64_t pitch, int cube_size, int depth
     });
 }
 
-int rc_legacy_scramble_actions(const uint32_t *seeds, const int32_t *counts, int count_uniform, int kmax, int64_t n, int cube_size,
-                                uint8_t *actions_out, int64_t pitch, void *stream) {
+// Which generator form runs (`variant` of rc_legacy_scramble_actions_ex; include/rubikhip.h RC_VARIANT_LEGACY_*): 0 = by kmax,
+// 1 = the LDS kernel alone, 2 + 16 * limit = the streaming kernel with `limit` outputs per lane (1..227; 0 = 227) + the fixup launch.
+// Default rule: a draw is accepted with probability 3/4, so k draws consume k / 0.75 outputs on average with a standard deviation of
+// sqrt(k) * 0.67: up to kmax = 128 (171 +- 7.5) the 227 streamed outputs are never short in practice, and when they are the fixup
+// launch redoes that wave -- the rule only decides which kernel does the bulk.
+constexpr int kLegacyStreamMax = 128;
+int rc_legacy_scramble_actions_ex(const uint32_t *seeds, const int32_t *counts, int count_uniform, int kmax, int64_t n, int cube_size,
+                                   uint8_t *actions_out, int64_t pitch, void *stream, int variant) {
     RC_NEED_INIT();
     if (!seeds || !actions_out || n < 0 || kmax < 0 || bad_pitch(pitch, n)) return fail(RC_EINVAL, "rc_legacy_scramble_actions: bad arguments%s");
+    if (!aligned16(actions_out)) return fail(RC_EINVAL, "rc_legacy_scramble_actions: actions_out must be 16-byte aligned%s");
     if (!counts && (count_uniform < 0 || count_uniform > kmax)) return fail(RC_EINVAL, "rc_legacy_scramble_actions: count_uniform must be in 0..kmax%s");
+    if (cube_size != 2 && cube_size != 3) return fail(RC_EINVAL, "cube_size must be 2 or 3%s");
+    const int mode = variant & 15, lim = variant >> 4;
+    if (variant < 0 || mode > 2 || lim > 227 || (mode != 2 && lim != 0)) return fail(RC_EINVAL, "rc_legacy_scramble_actions: unknown variant%s");
     if (n == 0 || kmax == 0) return RC_OK;
-    const int64_t blocks = (n + kWave - 1) / kWave;
-    RC_GRID(blocks);
-    const dim3 g((unsigned)blocks), b(kWave);
-    if (cube_size == 3) hipLaunchKernelGGL((k_legacy_actions<12>), g, b, 0, S(stream), seeds, counts, count_uniform, kmax, n, actions_out, pitch);
-    else if (cube_size == 2) hipLaunchKernelGGL((k_legacy_actions<6>), g, b, 0, S(stream), seeds, counts, count_uniform, kmax, n, actions_out, pitch);
-    else return fail(RC_EINVAL, "cube_size must be 2 or 3%s");
+    const int64_t waves = (n + kWave - 1) / kWave;
+    RC_GRID(waves);
+    const bool streamed = mode == 2 || (mode == 0 && kmax <= kLegacyStreamMax);
+    if (streamed) {
+        const dim3 g((unsigned)((n + 255) / 256)), b(256);
+        const int limit = lim ? lim : 227;
+        if (cube_size == 3) hipLaunchKernelGGL((k_legacy_actions_stream<12>), g, b, 0, S(stream), seeds, counts, count_uniform, kmax, n, actions_out, pitch, limit);
+        else hipLaunchKernelGGL((k_legacy_actions_stream<6>), g, b, 0, S(stream), seeds, counts, count_uniform, kmax, n, actions_out, pitch, limit);
+        RC_HIP(hipGetLastError());
+    }
+    const int64_t chunks = (waves + 3) / 4;
+    const dim3 g((unsigned)(streamed ? (chunks < 1024 ? chunks : 1024) : waves)), b(kWave);
+    if (cube_size == 3) hipLaunchKernelGGL((k_legacy_actions<12>), g, b, 0, S(stream), seeds, counts, count_uniform, kmax, n, actions_out, pitch, streamed ? 1 : 0);
+    else hipLaunchKernelGGL((k_legacy_actions<6>), g, b, 0, S(stream), seeds, counts, count_uniform, kmax, n, actions_out, pitch, streamed ? 1 : 0);
     RC_HIP(hipGetLastError());
     return RC_OK;
+}
+
+int rc_legacy_scramble_actions(const uint32_t *seeds, const int32_t *counts, int count_uniform, int kmax, int64_t n, int cube_size,
+                                uint8_t *actions_out, int64_t pitch, void *stream) {
+    return rc_legacy_scramble_actions_ex(seeds, counts, count_uniform, kmax, n, cube_size, actions_out, pitch, stream, 0);
 }
 
 int rc_is_solved(const uint8_t *stp, int64_t n, int64_t pitch, int cube_size, uint8_t *done, float *reward, void *stream) {
@@ -1597,6 +1740,7 @@ int rc_encode_ws(const uint8_t *stp, int64_t n, int64_t pitch, int cube_size, vo
 
 int rc_onehot_from_code_ex(const uint8_t *code, int64_t n, int64_t code_pitch, int cube_size, void *onehot, int fmt, void *stream, int variant) {
     RC_NEED_INIT();
+    if (int rc = check_variant(RC_OP_CODE_TO_DENSE, 12, variant)) return rc;
     const int sh = tile_shift(code_pitch, n, 20);
     if (!code || !aligned16(code) || n < 0 || sh < 0) return fail(RC_EINVAL, "bad code buffer / pitch%s");
     if (fmt < RC_FMT_U8 || fmt > RC_FMT_BF16 || !onehot || !aligned16(onehot)) return fail(RC_EINVAL, "rc_onehot_from_code: dense fmt and aligned buffer required%s");
@@ -1619,6 +1763,7 @@ int rc_onehot_from_code(const uint8_t *code, int64_t n, int64_t code_pitch, int 
 int rc_expand_children_ex(const uint8_t *in, int64_t n, int64_t pitch_in, int cube_size, uint8_t *children, uint8_t *child_solved,
                           uint8_t *child_code, int64_t pitch_out, void *stream, int variant) {
     RC_NEED_INIT();
+    if (int rc = check_variant(RC_OP_EXPAND, cube_size == 2 ? 6 : 12, variant)) return rc;
     const int sh_in = tile_shift(pitch_in, n), sh_out = tile_shift(pitch_out, n);
     if (!in || !aligned16(in) || n < 0 || sh_in < 0 || sh_out < 0) return fail(RC_EINVAL, "rc_expand_children: bad buffer / pitch%s");
     if (!children && !child_solved && !child_code) return fail(RC_EINVAL, "rc_expand_children: nothing to write%s");
@@ -1645,6 +1790,7 @@ static int adi_common(uint64_t seed, uint64_t stream_id, int64_t walk_offset, in
                       const uint8_t *actions_in, uint8_t *actions_out, uint8_t *parents, uint8_t *parent_code, uint8_t *children,
                       uint8_t *child_code, uint8_t *child_solved, uint8_t *family, void *stream, int variant) {
     RC_NEED_INIT();
+    if (int rc = check_variant(RC_OP_ADI, cube_size == 2 ? 6 : 12, variant)) return rc;
     if (family && !aligned16(family)) return fail(RC_EINVAL, "rc_adi_generate: buffers must be 16-byte aligned%s");
     const int sh = tile_shift(pitch, n_walks);
     if (n_walks < 0 || depth < 0 || sh < 0) return fail(RC_EINVAL, "rc_adi_generate: bad sizes / pitch%s");
@@ -1700,15 +1846,35 @@ int rc_family_layout(int cube_size, uint8_t *rows, int32_t *n_rows) {
     });
 }
 
-int rc_onehot_from_family(const uint8_t *family, int64_t n, int64_t pitch, int cube_size, void *onehot, int fmt, int64_t block_stride, void *stream) {
+int rc_onehot_from_family_depths(const uint8_t *family, int64_t n, int64_t pitch, int cube_size, void *onehot, int fmt, int64_t block_stride,
+                                 int n_depths, void *stream) {
     RC_NEED_INIT();
     if (cube_size != 3) return fail(RC_EINVAL, "rc_onehot_from_family: 3x3x3 only%s");
     const int sh = tile_shift(pitch, n, kFamily<Cube3>.nf);
     if (!family || !aligned16(family) || n < 0 || sh < 0) return fail(RC_EINVAL, "bad family buffer / pitch%s");
     if (fmt < RC_FMT_U8 || fmt > RC_FMT_BF16 || !onehot || !aligned16(onehot)) return fail(RC_EINVAL, "rc_onehot_from_family: dense fmt and aligned buffer required%s");
     if (block_stride < n) return fail(RC_EINVAL, "rc_onehot_from_family: block_stride must be >= n_cubes%s");
-    if (n == 0) return RC_OK;
-    return launch_family_to_dense<Cube3>(family, n, pitch, sh, onehot, fmt, block_stride, S(stream));
+    if (n_depths < 0 || n_depths > 0xffff) return fail(RC_EINVAL, "rc_onehot_from_family: n_depths must be in 0..65535%s");
+    if (n == 0 || n_depths == 0) return RC_OK;
+    const int64_t tiles = n <= pitch ? 1 : (n + pitch - 1) / pitch;
+    const FamilyDepths dp{n_depths, tiles * kFamily<Cube3>.nf * pitch, (int64_t)(Cube3::A + 1) * block_stride};
+    return launch_family_to_dense<Cube3>(family, n, pitch, sh, onehot, fmt, block_stride, dp, S(stream));
+}
+
+int rc_onehot_from_family(const uint8_t *family, int64_t n, int64_t pitch, int cube_size, void *onehot, int fmt, int64_t block_stride, void *stream) {
+    return rc_onehot_from_family_depths(family, n, pitch, cube_size, onehot, fmt, block_stride, 1, stream);
+}
+
+static int launch_targets(const TargetArgs &t, int n_depths, int cube_size, void *stream) {
+    const int64_t blocks = (t.n + 255) / 256;
+    RC_GRID(blocks);
+    if (n_depths > 65535) return fail(RC_EINVAL, "rc_adi_targets: at most 65535 depths per launch%s");
+    const dim3 g((unsigned)blocks, (unsigned)n_depths), b(256);
+    if (cube_size == 3) hipLaunchKernelGGL((k_adi_targets<12>), g, b, 0, S(stream), t);
+    else if (cube_size == 2) hipLaunchKernelGGL((k_adi_targets<6>), g, b, 0, S(stream), t);
+    else return fail(RC_EINVAL, "cube_size must be 2 or 3%s");
+    RC_HIP(hipGetLastError());
+    return RC_OK;
 }
 
 int rc_adi_targets(const float *child_value, const uint8_t *child_solved, const float *parent_value, const double *weight, int64_t n,
@@ -1717,39 +1883,61 @@ int rc_adi_targets(const float *child_value, const uint8_t *child_solved, const 
     if (n == 0) return RC_OK;                                  // nothing to assemble: empty outputs may be null pointers
     if (!child_value || !child_solved || !target_value || !target_policy || n < 0 || pitch < n) return fail(RC_EINVAL, "rc_adi_targets: bad arguments%s");
     if (error && (!parent_value || !weight)) return fail(RC_EINVAL, "rc_adi_targets: error needs parent_value and weight%s");
-    const int64_t blocks = (n + 255) / 256;
-    RC_GRID(blocks);
-    const dim3 g((unsigned)blocks), b(256);
-    if (cube_size == 3) hipLaunchKernelGGL((k_adi_targets<12>), g, b, 0, S(stream), child_value, child_solved, parent_value, weight, n, pitch, target_value, target_policy, error);
-    else if (cube_size == 2) hipLaunchKernelGGL((k_adi_targets<6>), g, b, 0, S(stream), child_value, child_solved, parent_value, weight, n, pitch, target_value, target_policy, error);
-    else return fail(RC_EINVAL, "cube_size must be 2 or 3%s");
-    RC_HIP(hipGetLastError());
-    return RC_OK;
+    const TargetArgs t{child_value, 0, pitch, child_solved, 0, pitch, parent_value, 0, weight, 0, n, target_value, target_policy, error, 1};
+    return launch_targets(t, 1, cube_size, stream);
+}
+
+int rc_adi_targets_depths(const float *child_value, int64_t cv_depth_stride, int64_t cv_child_stride, const uint8_t *child_solved,
+                          int64_t solved_pitch, const float *parent_value, int64_t pv_depth_stride, const double *weight, int64_t n,
+                          int n_depths, int cube_size, float *target_value, int32_t *target_policy, double *error, int64_t out_stride,
+                          void *stream) {
+    RC_NEED_INIT();
+    if (n == 0 || n_depths == 0) return RC_OK;
+    if (!child_value || !child_solved || !target_value || !target_policy || n < 0 || n_depths < 0 || solved_pitch < n || cv_child_stride < n ||
+        out_stride < n_depths)
+        return fail(RC_EINVAL, "rc_adi_targets_depths: bad arguments%s");
+    if (error && (!parent_value || !weight)) return fail(RC_EINVAL, "rc_adi_targets_depths: error needs parent_value and weight%s");
+    const int A = cube_size == 2 ? 6 : 12;
+    const TargetArgs t{child_value, cv_depth_stride, cv_child_stride, child_solved, (int64_t)A * solved_pitch, solved_pitch, parent_value, pv_depth_stride,
+                       weight, 1, n, target_value, target_policy, error, out_stride};
+    return launch_targets(t, n_depths, cube_size, stream);
 }
 
 static int facade_wait(uint8_t *host_out, uint32_t seq, void *stream, const char *who);
 
 // host_out is dereferenced by the HOST while polling and written by the KERNEL through its device alias: for hipHostMalloc'ed
 // memory the two addresses are equal, for hipHostRegister'ed memory (e.g. torch with pinned_use_cuda_host_register) they may
-// differ, so the kernel always gets attr.devicePointer.  The (host, device) pair of the last buffer is cached per thread;
-// rc_facade_release drops it (call it before freeing a buffer whose address may be reused by non-pinned memory).
-// The cache key is (host address, current device): an alias looked up for one device is never used on another.  A sequence number
-// of 1 (a caller's first use of a buffer: every CubeEnv starts its sequence there) always re-validates, so an address that was
-// freed and handed out again -- pinned or not -- is looked up afresh by its new owner.
+// differ, so the kernel always gets attr.devicePointer.  Validated (host, device ordinal) -> alias pairs are cached PROCESS-WIDE
+// (a short table behind a mutex: ~20 ns on a 10 us path), so rc_facade_release works from any thread -- Python runs __del__ wherever
+// the garbage collector happens to run.  A sequence number of 1 (a caller's first use of a buffer: every CubeEnv starts its sequence
+// there) always re-validates, so an address that was freed and handed out again -- pinned or not -- is looked up afresh by its new owner.
 struct FacadeAlias { const uint8_t *host; uint8_t *dev; int device; };
-static thread_local FacadeAlias t_alias{nullptr, nullptr, -1};
+static std::mutex g_alias_lock;
+static std::vector<FacadeAlias> g_alias;
+static void alias_drop(const uint8_t *host_out) {                            // caller holds the lock; NULL = everything
+    size_t k = 0;
+    for (size_t i = 0; i < g_alias.size(); ++i)
+        if (host_out != nullptr && g_alias[i].host != host_out) g_alias[k++] = g_alias[i];
+    g_alias.resize(k);
+}
 static int facade_check_host(const uint8_t *host_out, uint32_t seq, const char *who, uint8_t **dev_alias) {
     int device = -1;
     if (hipGetDevice(&device) != hipSuccess) return fail(RC_ENODEV, "no current HIP device%s");
-    if (host_out == t_alias.host && device == t_alias.device && seq != 1) { *dev_alias = t_alias.dev; return RC_OK; }
+    std::lock_guard<std::mutex> hold(g_alias_lock);
+    if (seq != 1)
+        for (const FacadeAlias &a : g_alias)
+            if (a.host == host_out && a.device == device) { *dev_alias = a.dev; return RC_OK; }
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes(&attr, host_out) != hipSuccess || attr.type != hipMemoryTypeHost || attr.devicePointer == nullptr) {
         (void)hipGetLastError();
-        if (host_out == t_alias.host) t_alias = {nullptr, nullptr, -1};
+        alias_drop(host_out);
         return fail(RC_EINVAL, "%s: host_out must be host-mapped pinned memory (hipHostMalloc / torch pin_memory)", who);
     }
-    t_alias = {host_out, static_cast<uint8_t *>(attr.devicePointer), device};
-    *dev_alias = t_alias.dev;
+    for (FacadeAlias &a : g_alias)
+        if (a.host == host_out && a.device == device) { a.dev = static_cast<uint8_t *>(attr.devicePointer); *dev_alias = a.dev; return RC_OK; }
+    if (g_alias.size() >= 256) g_alias.erase(g_alias.begin());             // callers that never release: forget the oldest
+    g_alias.push_back({host_out, static_cast<uint8_t *>(attr.devicePointer), device});
+    *dev_alias = g_alias.back().dev;
     return RC_OK;
 }
 
@@ -1799,7 +1987,8 @@ static int facade_wait(uint8_t *host_out, uint32_t seq, void *stream, const char
 }
 
 int rc_facade_release(const uint8_t *host_out) {
-    if (host_out == nullptr || host_out == t_alias.host) t_alias = {nullptr, nullptr, -1};
+    std::lock_guard<std::mutex> hold(g_alias_lock);
+    alias_drop(host_out);
     return RC_OK;
 }
 
@@ -1824,6 +2013,8 @@ int rc_facade_expand(const uint8_t *stp, int64_t pitch, int cube_size, uint8_t *
 int rc_describe_dispatch(int op, int cube_size, int64_t n, int depth, unsigned outputs, int fmt, int variant, char *buf, int buflen) {
     if (!buf || buflen < 16) return fail(RC_EINVAL, "rc_describe_dispatch: buffer too small%s");
     if (n <= 0) return fail(RC_EINVAL, "rc_describe_dispatch: n must be positive%s");
+    if (op != RC_OP_STEP && op != RC_OP_EXPAND && op != RC_OP_ADI && op != RC_OP_CODE_TO_DENSE) return fail(RC_EINVAL, "rc_describe_dispatch: unknown op%s");
+    if (int rc = check_variant(op, cube_size == 2 ? 6 : 12, variant)) return rc;
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
         const char *cube = T::SIZE == 3 ? "Cube3" : "Cube2";

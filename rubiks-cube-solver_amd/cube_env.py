@@ -25,8 +25,9 @@ from .tables import ACTION_NAMES, get_env_config, get_tables
 class CubeEnv:
     metadata = {"render_modes": ["human", "rgb_array"]}
 
-    def __init__(self, device, cube_size=2, compute_device=None, _backend=None):
-        """device: torch device for model tensors (e.g. torch.device('cpu:0')); cube_size: 2 or 3."""
+    def __init__(self, device, cube_size=2, compute_device=None):
+        """device: torch device for model tensors (e.g. torch.device('cpu:0')); cube_size: 2 or 3;
+        compute_device: the HIP device the cube lives on (default: `device` if it is one, else the current HIP device)."""
         self.cube_size = cube_size
         self.device = device
         self.action_to_sim_action = {  # cube_env.py:24-28
@@ -39,17 +40,21 @@ class CubeEnv:
         if cube_size not in (2, 3):
             raise NotImplementedError  # get_env_config / init_state, cube_env.py:30,44
         self.state_dim, self.action_dim = get_env_config(cube_size)
-        if _backend is None:
-            from .vec_env import VecCubeEnv
-            if compute_device is None:
-                d = torch.device(device) if not isinstance(device, torch.device) else device
-                compute_device = d if d.type == "cuda" else "cuda"
-            _backend = VecCubeEnv(1, compute_device, cube_size, obs="onehot", onehot_dtype=torch.uint8)
-        self._vec = _backend
+        self._vec = self._make_vec(compute_device)
         self._sim_cache = None
         self._cube_cache = None
         self._fast = None  # pinned result buffer + cached call arguments of the facade step path
+        self._adi_plans = {}  # get_random_samples: static buffers (and, with adi_graph, the captured hipGraph) per call shape
+        self.adi_graph = False  # True: get_random_samples replays its one-hot -> net -> targets body as a hipGraph (adi.AdiPlan)
         self.init_state()
+
+    def _make_vec(self, compute_device):
+        """The one-cube device state behind the facade: a VecCubeEnv(1) on a HIP device.  There is no other implementation."""
+        from .vec_env import VecCubeEnv
+        if compute_device is None:
+            d = torch.device(self.device) if not isinstance(self.device, torch.device) else self.device
+            compute_device = d if d.type == "cuda" else "cuda"
+        return VecCubeEnv(1, compute_device, self.cube_size, obs="onehot", onehot_dtype=torch.uint8)
 
     # ------------------------------------------------------------------ state attributes
     @property
@@ -95,20 +100,12 @@ class CubeEnv:
             np.random.seed(seed)
         action_sequence = np.random.randint(self.action_dim, size=scramble_count)
         np.random.set_state(origin_state)
-        if hasattr(self._vec, "stickers"):
-            ops.fill_solved(self._vec.stickers, 1, self.cube_size)
-            self._sim_cache = None
-            if len(action_sequence) == 0:
-                self._cube_cache = None
-                raise UnboundLocalError("local variable 'state' referenced before assignment")  # cube_env.py:69
-            return self.step_many([int(a) for a in action_sequence])[0]
-        self.init_state()
-        if len(action_sequence) == 0:
-            raise UnboundLocalError("local variable 'state' referenced before assignment")  # cube_env.py:69
-        obs = self._vec.reset(actions=action_sequence.reshape(1, -1).astype(np.uint8), scramble_count=len(action_sequence))
+        self._fill_solved()
         self._sim_cache = None
-        self._cube_cache = self._typed(obs[0])
-        return self._cube_cache
+        if len(action_sequence) == 0:
+            self._cube_cache = None
+            raise UnboundLocalError("local variable 'state' referenced before assignment")  # cube_env.py:69
+        return self.step_many([int(a) for a in action_sequence])[0]
 
     def step(self, action):
         """action: int 0..A-1 in the order U,U',F,F',R,R'[,D,D',B,B',L,L'].
@@ -118,11 +115,7 @@ class CubeEnv:
         names = self.action_to_sim_action[self.cube_size]
         sim_action = names[action]  # IndexError / TypeError exactly like the reference's list lookup
         idx = names.index(sim_action)  # moveInds, py333.py:41-44,221
-        if hasattr(self._vec, "stickers"):
-            onehot, solved = self._step_device(idx)
-        else:  # test-only backends
-            obs, _, done, _ = self._vec.step(torch.tensor([idx], dtype=torch.uint8))
-            onehot, solved = obs[0].cpu().numpy(), bool(done[0].item())
+        onehot, solved = self._step_device(idx)
         self._sim_cache = None
         self._cube_cache = onehot.astype(np.int64) if self.cube_size == 3 else onehot.astype(np.float64)
         return self._cube_cache, (1.0 if solved else -1.0), solved, {}
@@ -142,6 +135,10 @@ class CubeEnv:
         f[5] = (f[5] % 0xFFFFFFFF) + 1
         return f
 
+    # The four methods below are the facade's whole contact with the device: each is ONE launch of librubikhip.so.
+    def _fill_solved(self):
+        ops.fill_solved(self._vec.stickers, 1, self.cube_size)
+
     def _step_device(self, idx):
         f = self._facade()
         v = self._vec
@@ -158,16 +155,19 @@ class CubeEnv:
         (mcts.py:52-81).  actions: ints 0..A-1 (IndexError otherwise, like step)."""
         names = self.action_to_sim_action[self.cube_size]
         acts = bytes(names.index(names[a]) for a in actions)        # same IndexError / TypeError as step()
+        onehot, solved = self._steps_device(acts)
+        self._sim_cache = None
+        self._cube_cache = onehot.astype(np.int64) if self.cube_size == 3 else onehot.astype(np.float64)
+        return self._cube_cache, (1.0 if solved else -1.0), solved, {}
+
+    def _steps_device(self, acts):
         f = self._facade()
         v = self._vec
         rc = f[8](f[3], f[4], self.cube_size, acts, len(acts), f[2], f[5], 1, _lib.stream_ptr(v.device))
         if rc:
             _lib.check(rc)
         R, C = self.state_dim
-        onehot, solved = f[1][:R * C].reshape(R, C), bool(f[1][496])
-        self._sim_cache = None
-        self._cube_cache = onehot.astype(np.int64) if self.cube_size == 3 else onehot.astype(np.float64)
-        return self._cube_cache, (1.0 if solved else -1.0), solved, {}
+        return f[1][:R * C].reshape(R, C), bool(f[1][496])
 
     def expand_host(self, dense=False):
         """All children of the CURRENT state in one launch, results on the host (mcts.py:83-113, cube_env.py:212-236):
@@ -217,7 +217,7 @@ class CubeEnv:
         moves come from np.random.randint(action_dim, size=sample_scramble_count) on the global legacy
         RNG, exactly as the reference draws them; walks, expansion, one-hots and targets run on the GPU.  A sink with
         `append_batch` (replay.TensorReplayBuffer) receives the batch as tensors; anything else gets the reference's dicts."""
-        from .adi import adi_samples, samples_to_dicts
+        from .adi import AdiPlan, samples_to_dicts
 
         if sample_cube_count <= 0:
             return
@@ -225,8 +225,16 @@ class CubeEnv:
                             for _ in range(sample_cube_count)]).astype(np.uint8)
         if sample_scramble_count > 0:
             tensor_sink = hasattr(replay_buffer, "append_batch")         # replay.TensorReplayBuffer: no per-sample dicts
-            res = adi_samples(model, self.cube_size, sample_cube_count, sample_scramble_count, temperature,
-                              device=self._vec.device, model_device=self.device, actions=actions, want_state_dense=not tensor_sink)
+            # train.py:152-155 calls this every epoch with one shape and one model object: the buffers (and with adi_graph the
+            # captured hipGraph) of that shape are kept between calls
+            key = (id(model), sample_scramble_count, sample_cube_count, float(temperature), not tensor_sink, bool(self.adi_graph))
+            plan = self._adi_plans.get(key)
+            if plan is None or plan.model is not model:
+                self._adi_plans.clear()
+                plan = self._adi_plans[key] = AdiPlan(model, self.cube_size, sample_cube_count, sample_scramble_count, temperature,
+                                                      device=self._vec.device, model_device=self.device, want_state_dense=not tensor_sink,
+                                                      graph=bool(self.adi_graph))
+            res = plan.run(actions)
             if tensor_sink:
                 replay_buffer.append_batch(res)
             else:                                                         # the reference's own ReplayBuffer / any list-like sink
@@ -243,24 +251,13 @@ class CubeEnv:
         """(target_value, target_policy, error) of the CURRENT state (cube_env.py:196-252)."""
         if self.cube_size not in (2, 3):
             raise NotImplementedError
-        if hasattr(self._vec, "stickers"):
-            _, _, solved, child_onehot = self.expand_host(dense=True)
-        else:  # test-only backends
-            ex = self._vec.expand(codes=True)
-            solved = ex["child_solved"][:, 0].cpu().numpy().astype(bool)
-            child_onehot = None
+        _, _, solved, child_onehot = self.expand_host(dense=True)
         reward = -1.0
         if solved.any():  # lowest solved action wins, value exactly 1.0 (cube_env.py:229-232)
             reward, target_value, target_policy = 1.0, 1.0, int(np.argmax(solved))
         if reward != 1.0:
             A = self.action_dim
-            if child_onehot is not None:
-                dense = torch.from_numpy(child_onehot).float()
-            else:
-                dense = torch.empty((A, *self.state_dim), dtype=torch.float32, device=self._vec.device)
-                for a in range(A):
-                    ops.onehot_from_code(ex["child_code"][a], 1, self.cube_size, dense[a:a + 1])
-            next_state_tensor = dense.to(self.device)
+            next_state_tensor = torch.from_numpy(child_onehot).float().to(self.device)
             reward_tensor = torch.tensor([-1.0] * A, device=self.device)
             with torch.no_grad():
                 next_value, _ = model(next_state_tensor)
@@ -306,7 +303,9 @@ class CubeEnv:
         other = object.__new__(CubeEnv)
         for k, v in self.__dict__.items():
             if k == "_vec":
-                other._vec = self._vec.clone(lean=True) if hasattr(self._vec, "stickers") else self._vec.clone()
+                other._vec = self._vec.clone(lean=True)
+            elif k == "_adi_plans":
+                other._adi_plans = {}  # static device buffers are not shared between copies
             elif k == "device":
                 other.device = self.device
             elif k == "_fast":

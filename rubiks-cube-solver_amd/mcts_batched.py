@@ -190,12 +190,29 @@ class BatchedMCTS:
         self.code = ops.alloc_code(self.n, cube_size, self.dev, root_stickers.shape[-1])
         self.ex = ops.expand_buffers(self.n, cube_size, self.dev, root_stickers.shape[-1], children=False, codes=True)
         SL = ops.N_SLOTS[cube_size]
-        # results in the host's layout ([root][...]) are produced ON the device (three small transposing copies, inside the
-        # captured graph), so the download needs no reshuffle on the host
-        self._leaf_aos = torch.empty((self.n, SL), dtype=torch.uint8, device=self.dev)
-        self._child_aos = torch.empty((self.n, self.A, SL), dtype=torch.uint8, device=self.dev)
-        self._solved_aos = torch.empty((self.n, self.A), dtype=torch.uint8, device=self.dev)
-        self.graph, self._graphs, self._paths, self._host = bool(graph), {}, None, None
+        # Results travel to the host as ONE block: leaf codes, child codes, solved flags, leaf values and policies are produced in the
+        # host's layout ([root][...]) ON the device (small transposing copies inside the captured graph) as views of one device
+        # buffer, which one D2H copy brings into one pinned buffer; the trees read the pinned views in place (round 4 issued five
+        # copies and then copied every array again on the host: 172 us per simulation of 4096 roots).
+        n, A = self.n, self.A
+        parts = (("leaf", n * SL), ("child", n * A * SL), ("solved", n * A), ("value", 4 * n), ("policy", 4 * n * A))
+        off, total = {}, 0
+        for name, size in parts:
+            off[name] = (total, size)
+            total = -(-(total + size) // 256) * 256
+        self._pack_dev = torch.zeros(total, dtype=torch.uint8, device=self.dev)
+        self._pack_host = torch.zeros(total, dtype=torch.uint8).pin_memory() if self.dev.type == "cuda" else torch.zeros(total, dtype=torch.uint8)
+        dv = lambda name: self._pack_dev[off[name][0]:off[name][0] + off[name][1]]
+        self._leaf_aos = dv("leaf").view(n, SL)
+        self._child_aos = dv("child").view(n, A, SL)
+        self._solved_aos = dv("solved").view(n, A)
+        self._value_dev = dv("value").view(torch.float32)
+        self._policy_dev = dv("policy").view(torch.float32).view(n, A)
+        hp = self._pack_host.numpy()
+        hv = lambda name: hp[off[name][0]:off[name][0] + off[name][1]]
+        self._host = (hv("leaf").reshape(n, SL), hv("child").reshape(n, A, SL), hv("solved").reshape(n, A),
+                      hv("value").view(np.float32), hv("policy").view(np.float32).reshape(n, A))
+        self.graph, self._graphs, self._paths, self._paths_host = bool(graph), {}, None, None
 
     def __getattr__(self, name):
         # result views of the native trees under the names the Python tree uses (solution, sims_used, trees[r][b"root"]);
@@ -229,27 +246,36 @@ class BatchedMCTS:
         ops.encode(self.work, n, cs, self.code, _lib.FMT_CODE)
         ops.onehot_from_code(self.code, n, cs, self.onehot)
         value, logits = self.model(self.onehot)
-        policy = torch.softmax(logits, dim=-1)          # model.py:89
+        if logits.dtype == torch.float32:
+            torch.softmax(logits, dim=-1, out=self._policy_dev)                 # model.py:89, straight into the download block
+        else:
+            self._policy_dev.copy_(torch.softmax(logits, dim=-1))
+        self._value_dev.copy_(value.reshape(-1))
         self._leaf_aos.copy_(ops.to_aos(self.code, n))
         cc = self.ex["child_code"]                                              # [A, tiles, SLOTS, pitch]
         self._child_aos.copy_(cc.permute(1, 3, 0, 2).reshape(-1, self.A, cc.shape[2])[:n])
         self._solved_aos.copy_(self.ex["child_solved"][:, :n].t())
-        return value, policy
 
     @torch.no_grad()
-    def leaves_step(self, paths):
+    def leaves_step(self, paths, copy=True):
         """Device part of one simulation for `paths` (uint8 [R, depth], no-op padded).  With graph=True the
         kernel sequence is captured once per depth bucket as a hipGraph (paths padded with the no-op up to the
-        bucket) and replayed: one launch instead of ~15 (DESIGN.md "Config 5").  Returns host arrays."""
+        bucket) and replayed: one launch instead of ~15 (DESIGN.md "Config 5").  One upload (the paths, from a pinned staging
+        buffer), one download (the packed result block), one synchronisation.  Returns host arrays (leaf code [R, SLOTS], child code
+        [R, A, SLOTS], solved [R, A], value [R], policy [R, A]); copy=False hands out views of the pinned block, valid until
+        the next call."""
         n = self.n
         depth = paths.shape[1]
         if self._paths is None or self._paths.shape[0] < depth:
             cap = max(16, 1 << max(depth - 1, 0).bit_length())
             self._paths = torch.full((cap, _lib.pitch_for(n)), self.A, dtype=torch.uint8, device=self.dev)
+            self._paths_host = torch.full((cap, _lib.pitch_for(n)), self.A, dtype=torch.uint8).pin_memory()
             self._graphs = {}
-        self._paths.fill_(self.A)
+        ph = self._paths_host.numpy()
+        ph.fill(self.A)
         if depth:
-            self._paths[:depth, :n] = torch.from_numpy(np.ascontiguousarray(paths.T)).to(self.dev)
+            ph[:depth, :n] = paths.T
+        self._paths.copy_(self._paths_host, non_blocking=True)
         if self.graph:
             bucket = 0 if depth == 0 else max(4, 1 << (depth - 1).bit_length())      # replay length: no-op padded
             bucket = min(bucket, self._paths.shape[0])
@@ -261,22 +287,18 @@ class BatchedMCTS:
                 torch.cuda.current_stream(self.dev).wait_stream(s)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    out = self._device_step(bucket)
-                self._graphs[bucket] = (g, out)
-            g, (value, policy) = self._graphs[bucket]
-            g.replay()
+                    self._device_step(bucket)
+                self._graphs[bucket] = g
+            self._graphs[bucket].replay()
         else:
-            value, policy = self._device_step(depth)
-        # one batch of downloads into pinned memory, one sync
-        if self._host is None:
-            pin = lambda t: torch.empty(t.shape, dtype=t.dtype).pin_memory()
-            self._host = [pin(self._leaf_aos), pin(self._child_aos), pin(self._solved_aos), pin(value), pin(policy)]
-        for h, d in zip(self._host, (self._leaf_aos, self._child_aos, self._solved_aos, value, policy)):
-            h.copy_(d, non_blocking=True)
+            self._device_step(depth)
+        self._pack_host.copy_(self._pack_dev, non_blocking=True)
         torch.cuda.current_stream(self.dev).synchronize()
-        code_h, cc_h, cs_h, v_h, p_h = (h.numpy() for h in self._host)
-        # copies: the pinned buffers are overwritten by the next simulation (the Python tree keeps policy rows)
-        return code_h.copy(), cc_h.copy(), cs_h.astype(bool), v_h.reshape(-1).copy(), p_h.copy()
+        code_h, cc_h, cs_h, v_h, p_h = self._host
+        if not copy:
+            return code_h, cc_h, cs_h, v_h, p_h
+        # copies: the pinned block is overwritten by the next simulation (the Python tree keeps policy rows)
+        return code_h.copy(), cc_h.copy(), cs_h.astype(bool), v_h.copy(), p_h.copy()
 
     def sync_rngs(self):
         """Write the per-root generators' current states back into the `random.Random` objects passed as `rngs` (native trees
@@ -288,7 +310,7 @@ class BatchedMCTS:
         """One simulation for every unsolved root.  Returns the number of roots solved so far."""
         if self.native is not None:
             paths = self.native.select()                                          # R tree descents (C++)
-            leaf_code, child_code, solved, value, policy = self.leaves_step(paths)   # device: replay, expand, encode, net
+            leaf_code, child_code, solved, value, policy = self.leaves_step(paths, copy=False)   # device: replay, expand, encode, net
             done = self.native.update(leaf_code, child_code, solved, value, policy)  # R insertions + back-propagations (C++)
             self._sims = getattr(self, "_sims", 0) + 1
             if self._sims % 16 == 0 and _lib.read_status(self.dev) & _lib.STATUS_BAD_ACTION:

@@ -183,10 +183,11 @@ def scramble(st, n, cube_size, depth, seed=0, stream_id=0, walk_offset=0, action
                             ptr(actions_out), ap, ptr(done), ptr(reward), stream_ptr(st.device)))
 
 
-def legacy_scramble_actions(seeds, cube_size, scramble_count, device=None):
+def legacy_scramble_actions(seeds, cube_size, scramble_count, device=None, variant=0):
     """The reference's reset(seed, k) draws for every env, computed on the device (numpy legacy MT19937 +
     masked rejection, cube_env.py:62-68).  seeds: int tensor / sequence [n] (0 <= seed < 2**32);
-    scramble_count: one int or one int per env.  Returns (actions uint8 [kmax, pitch] with no-op padding, kmax)."""
+    scramble_count: one int or one int per env.  Returns (actions uint8 [kmax, pitch] with no-op padding, kmax).
+    variant: which generator form runs (include/rubikhip.h RC_VARIANT_LEGACY_*; tests and benchmarks only)."""
     _, A, _ = _size(cube_size)
     dev = torch.device(device) if device is not None else (seeds.device if isinstance(seeds, torch.Tensor) else torch.device("cuda"))
     s = torch.as_tensor(seeds)
@@ -206,7 +207,7 @@ def legacy_scramble_actions(seeds, cube_size, scramble_count, device=None):
     pitch = _lib.pitch_for(n)
     out = torch.full((max(kmax, 1), pitch), A, dtype=torch.uint8, device=dev)      # pad columns / rows hold the no-op
     _lib.init(dev)
-    check(lib().rc_legacy_scramble_actions(ptr(s32), ptr(counts), uniform, kmax, n, cube_size, ptr(out), pitch, stream_ptr(dev)))
+    check(lib().rc_legacy_scramble_actions_ex(ptr(s32), ptr(counts), uniform, kmax, n, cube_size, ptr(out), pitch, stream_ptr(dev), variant))
     return out, kmax
 
 
@@ -241,18 +242,24 @@ def onehot_from_code(code, n, cube_size, onehot, variant=0):
     check(lib().rc_onehot_from_code_ex(ptr(code), n, cp, cube_size, ptr(onehot), fmt, stream_ptr(code.device), variant))
 
 
-def onehot_from_family(family, n, cube_size, onehot, block_stride):
-    """One depth's FAMILY rows ([tiles, NF, pitch] or [NF, pitch], n walks) -> the dense one-hots of all A children and the parent in ONE
-    launch: child a fills onehot[a * block_stride : a * block_stride + n], the parent onehot[A * block_stride : ...] (3x3x3)."""
+def onehot_from_family(family, n, cube_size, onehot, block_stride, n_depths=1):
+    """FAMILY rows of `n_depths` consecutive depths ([n_depths, tiles, NF, pitch]; one depth may drop the leading axis; n walks) -> the
+    dense one-hots of all A children and the parent of every depth in ONE launch: depth g, child a fills
+    onehot[(g * (A + 1) + a) * block_stride : ... + n], the parent is block a = A (3x3x3)."""
     _, A, _ = _size(cube_size)
     nf = _lib.family_layout(cube_size)[0]
-    pitch = _tiled(family, nf, n, "onehot_from_family")
+    one = family if n_depths == 1 and family.dim() <= 3 else family[0]
+    pitch = _tiled(one, nf, n, "onehot_from_family")
+    if n_depths != 1 or family.dim() > 3:
+        if family.dim() != 4 or family.shape[0] != n_depths or not family.is_contiguous():
+            raise RubikHipError(f"onehot_from_family: {n_depths} depths need a contiguous [n_depths, tiles, {nf}, pitch] buffer")
     fmt = _lib.fmt_of(onehot.dtype)
     R, C = STATE_DIM[cube_size]
-    if not onehot.is_cuda or not onehot.is_contiguous() or onehot.dim() != 3 or tuple(onehot.shape[1:]) != (R, C) or onehot.shape[0] < A * block_stride + n:
-        raise RubikHipError(f"onehot_from_family: need a contiguous HIP tensor [>= {A} * block_stride + n, {R}, {C}]")
+    rows = (n_depths * (A + 1) - 1) * block_stride + n
+    if not onehot.is_cuda or not onehot.is_contiguous() or onehot.dim() != 3 or tuple(onehot.shape[1:]) != (R, C) or onehot.shape[0] < rows:
+        raise RubikHipError(f"onehot_from_family: need a contiguous HIP tensor [>= (n_depths * {A + 1} - 1) * block_stride + n, {R}, {C}]")
     _lib.init(family.device)
-    check(lib().rc_onehot_from_family(ptr(family), n, pitch, cube_size, ptr(onehot), fmt, block_stride, stream_ptr(family.device)))
+    check(lib().rc_onehot_from_family_depths(ptr(family), n, pitch, cube_size, ptr(onehot), fmt, block_stride, n_depths, stream_ptr(family.device)))
 
 
 def _tiles_of(n, pitch):
@@ -397,3 +404,34 @@ def adi_targets(child_value, child_solved, n, cube_size, parent_value=None, weig
     check(lib().rc_adi_targets(ptr(child_value), ptr(child_solved), ptr(parent_value), ptr(weight), n, pitch, cube_size,
                                ptr(tv), ptr(tp), ptr(err), stream_ptr(dev)))
     return tv, tp, err
+
+
+def adi_targets_depths(child_value, cv_depth_stride, cv_child_stride, child_solved, parent_value, pv_depth_stride, weight, n, n_depths, cube_size,
+                       target_value, target_policy, error):
+    """rc_adi_targets for a GROUP of depths straight out of the value net's output (cube_env.py:229-232,239-251), results walk-major.
+    child_value / parent_value: float32 views INTO the net's output; element [g, a, w] of the former sits at g * cv_depth_stride +
+    a * cv_child_stride + w, [g, w] of the latter at g * pv_depth_stride + w.  child_solved: uint8 [n_depths, A, Wp] (contiguous slice of
+    the generator's flags).  weight: float64 [n_depths] (d ** -temperature per depth).  target_value / target_policy / error: 2-D views
+    [>= n, >= n_depths] of walk-major outputs whose last dimension is contiguous (stride(0) = elements between walks)."""
+    _, A, _ = _size(cube_size)
+    if child_solved.dtype != torch.uint8 or child_solved.dim() != 3 or tuple(child_solved.shape[:2]) != (n_depths, A) or not child_solved.is_contiguous():
+        raise RubikHipError("adi_targets_depths: child_solved must be contiguous uint8 [n_depths, A, Wp]")
+    wp = child_solved.shape[2]
+    for t, dt, what in ((child_value, torch.float32, "child_value"), (parent_value, torch.float32, "parent_value"), (weight, torch.float64, "weight")):
+        if t.dtype != dt or not t.is_cuda:
+            raise RubikHipError(f"adi_targets_depths: {what} must be a {dt} HIP tensor")
+    if weight.numel() < n_depths or not weight.is_contiguous():
+        raise RubikHipError("adi_targets_depths: need one contiguous weight per depth")
+    if child_value.numel() < (n_depths - 1) * cv_depth_stride + (A - 1) * cv_child_stride + n or parent_value.numel() < (n_depths - 1) * pv_depth_stride + n:
+        raise RubikHipError("adi_targets_depths: value views are too short for the strides given")
+    stride = None
+    for t, dt, what in ((target_value, torch.float32, "target_value"), (target_policy, torch.int32, "target_policy"), (error, torch.float64, "error")):
+        if t.dtype != dt or not t.is_cuda or t.dim() != 2 or t.shape[0] < n or t.shape[1] < n_depths or t.stride(1) != 1:
+            raise RubikHipError(f"adi_targets_depths: {what} must be a {dt} HIP view [>= n, >= n_depths] with a contiguous last dimension")
+        if stride is not None and t.stride(0) != stride:
+            raise RubikHipError("adi_targets_depths: the three outputs must share one walk stride")
+        stride = t.stride(0)
+    dev = child_solved.device
+    _lib.init(dev)
+    check(lib().rc_adi_targets_depths(ptr(child_value), cv_depth_stride, cv_child_stride, ptr(child_solved), wp, ptr(parent_value), pv_depth_stride,
+                                      ptr(weight), n, n_depths, cube_size, ptr(target_value), ptr(target_policy), ptr(error), stride, stream_ptr(dev)))

@@ -1,0 +1,280 @@
+"""Round 5: the ADI pipeline as ONE generator launch + one net forward per GROUP of depths (adi.AdiPlan), the multi-depth forms of the
+family writer and of the target assembly, the hipGraph path, and the two forms of the legacy-numpy generator.  Every check is against
+the CPU oracle, numpy itself, or the committed reference fixtures."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from rubiks_cube_solver_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def L():
+    from rubiks_cube_solver_amd import _lib
+    return _lib
+
+
+def _linear_model(cs, device="cuda", seed=0):
+    """value = <one-hot, w> + b as a batched torch callable (exact in float32 up to summation order)."""
+    R, C = (20, 24) if cs == 3 else (7, 21)
+    A = 12 if cs == 3 else 6
+    rng = np.random.default_rng(seed)
+    w = torch.tensor(rng.standard_normal(R * C).astype(np.float32), device=device)
+    b = 0.25
+
+    def model(x):
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+        return (x.reshape(x.shape[0], -1).float() @ w + b).unsqueeze(-1), torch.zeros(x.shape[0], A, device=x.device)
+    return model, w.cpu().numpy().astype(np.float64).reshape(R, C), b
+
+
+def _onehot_value(code, w, cs):
+    """<one-hot(code), w> on the host: 3x3x3 row = slot, column = code; 2x2x2 row = code // 3, column = slot * 3 + code % 3."""
+    code = code.astype(np.int64)
+    if cs == 3:
+        return w[np.arange(20), code].sum(-1)
+    return w[code // 3, np.arange(7) * 3 + code % 3].sum(-1)
+
+
+def _expected(oracle, cs, W, D, T, w, b, **adi_kw):
+    exp = oracle.adi(cs, W, D, want_children=False, threads=4, **adi_kw)
+    v_child = _onehot_value(exp["child_code"], w, cs) + b - 1.0                        # [W, D, A]
+    solved = exp["child_solved"].astype(bool)
+    tv = np.where(solved.any(-1), 1.0, v_child.max(-1))
+    tp = np.where(solved.any(-1), np.argmax(solved, -1), np.argmax(v_child, -1))
+    srt = np.sort(v_child, -1)
+    tie = (srt[..., -1] - srt[..., -2] < 1e-4) & ~solved.any(-1)
+    v_par = _onehot_value(exp["parent_code"], w, cs) + b
+    err = np.abs(v_par - tv) * np.arange(1, D + 1, dtype=np.float64)[None, :] ** -T
+    return exp, tv, tp, tie, err
+
+
+def _check(res, exp, tv, tp, tie, err, D):
+    assert (res["actions"].cpu().numpy() == exp["actions"]).all()
+    assert (res["state_code"].cpu().numpy() == exp["parent_code"]).all()
+    assert np.allclose(res["target_value"].cpu().numpy(), tv, atol=2e-5)
+    got = res["target_policy"].cpu().numpy()
+    assert ((got == tp) | tie).all() and (got == tp).mean() > 0.99
+    assert np.allclose(res["error"].cpu().numpy(), err, atol=2e-5)
+    assert (res["scramble_count"].cpu().numpy() == np.arange(1, D + 1)[None, :]).all()
+
+
+@pytest.mark.parametrize("cs", [3, 2])
+def test_adi_plan_groups_chunks_and_graph(oracle, cs):
+    """The same samples whatever the grouping: every depth in one forward, one depth per forward, several groups, several chunks of
+    walks, and the hipGraph replay (two runs with different seeds through ONE captured graph)."""
+    from rubiks_cube_solver_amd.adi import AdiPlan, adi_samples
+    model, w, b = _linear_model(cs)
+    T = 0.7
+    R, C = (20, 24) if cs == 3 else (7, 21)
+    A1 = 13 if cs == 3 else 7
+    row = R * C * 4
+    cases = [(333, 11, 1 << 30, "one group"), (333, 11, A1 * row * 336, "one depth per forward"), (333, 11, 4 * A1 * row * 336 + 5, "groups of 4 + a rest of 3"),
+             (2500, 5, A1 * row * 1100, "chunks of 1024 walks + a rest"), (20000, 3, 1 << 30, "several generator tiles")]
+    for W, D, budget, what in cases:
+        exp = _expected(oracle, cs, W, D, T, w, b, seed=5, stream=3)
+        res = adi_samples(model, cs, W, D, T, device="cuda", seed=5, stream_id=3, dense_budget_bytes=budget, want_state_dense=W < 1000)
+        _check(res, *exp, D)
+        if W < 1000:
+            oh = res["state"]
+            assert tuple(oh.shape) == (W, D, R, C) and int(oh.sum()) == W * D * (20 if cs == 3 else 7)
+            code = exp[0]["parent_code"].astype(np.int64)
+            want = np.zeros((W, D, R, C), np.uint8)
+            if cs == 3:
+                np.put_along_axis(want, code[..., None], 1, -1)
+            else:
+                wi, di, si = np.meshgrid(np.arange(W), np.arange(D), np.arange(7), indexing="ij")
+                want[wi, di, code // 3, si * 3 + code % 3] = 1
+            assert (oh.cpu().numpy() == want).all(), what
+    # the plan object: geometry, then eager and graph runs over the same static buffers
+    plan = AdiPlan(model, cs, 333, 11, T, dense_budget_bytes=4 * A1 * row * 336 + 5)
+    assert plan.group == (4 if cs == 3 else 2) and plan.chunk == 333 and len(plan.chunks) == 1     # 2x2x2 blocks are padded to 512 walks
+    plan = AdiPlan(model, cs, 2500, 5, T, dense_budget_bytes=A1 * row * 1100)
+    assert plan.chunk == 1024 and [c[1] for c in plan.chunks] == [1024, 1024, 452]
+    gplan = AdiPlan(model, cs, 777, 9, T, graph=True)
+    for seed in (21, 22, 23):                                          # run 1 captures, runs 2 and 3 replay
+        res = gplan.run(seed=seed, stream_id=1)
+        _check(res, *_expected(oracle, cs, 777, 9, T, w, b, seed=seed, stream=1), 9)
+    assert len(gplan._graphs) == 1
+    acts = np.random.default_rng(9).integers(0, 12 if cs == 3 else 6, (777, 9), dtype=np.uint8)
+    res = gplan.run(actions=acts)                                      # replayed moves through the same graph (host upload outside it)
+    _check(res, *_expected(oracle, cs, 777, 9, T, w, b, actions_in=acts), 9)
+    again = adi_samples(model, cs, 777, 9, T, graph=True, actions=torch.from_numpy(acts).cuda())
+    again2 = adi_samples(model, cs, 777, 9, T, graph=True, actions=acts)
+    for k in ("state_code", "target_value", "target_policy", "error", "actions"):
+        assert torch.equal(again[k], again2[k]) and torch.equal(again[k], res[k])
+    assert again["error"].data_ptr() != again2["error"].data_ptr()    # adi_samples hands out copies, not the plan's buffers
+    from rubiks_cube_solver_amd import adi
+    assert len(adi._plans) == 1
+    adi.release_plans()
+    with pytest.raises(ValueError):
+        AdiPlan(model, cs, 10, 2, T, model_device="cpu", graph=True)
+    empty = adi_samples(model, cs, 0, 4, T)
+    assert tuple(empty["target_value"].shape) == (0, 4) and tuple(empty["state_code"].shape) == (0, 4, 20 if cs == 3 else 7)
+
+
+def test_family_and_targets_depth_groups_match_single_depth_launches(ops, L, oracle):
+    """rc_onehot_from_family_depths / rc_adi_targets_depths against their one-depth forms (which earlier tests pin to the oracle):
+    identical bytes, for packed block strides, every dense format, one tile and several tiles."""
+    for n, D, bs in ((333, 6, 336), (5000, 3, 5000), (40000, 2, 40008)):
+        pitch, bufs = ops.adi_buffers(n, D, 3, "cuda", family=True)
+        ops.adi_generate(n, D, 3, pitch, "cuda", seed=3, stream_id=1, **bufs)
+        for dt in (torch.float32, torch.bfloat16, torch.float16, torch.uint8):
+            one = torch.zeros((D, 13 * bs, 20, 24), dtype=dt, device="cuda")
+            for d in range(D):
+                ops.onehot_from_family(bufs["family"][d], n, 3, one[d], block_stride=bs)
+            many = torch.zeros((D * 13 * bs, 20, 24), dtype=dt, device="cuda")
+            ops.onehot_from_family(bufs["family"], n, 3, many, block_stride=bs, n_depths=D)
+            assert torch.equal(many.view(D, 13 * bs, 20, 24), one), (n, dt)
+            part = torch.zeros(((D - 1) * 13 * bs, 20, 24), dtype=dt, device="cuda")          # a sub-range of depths
+            ops.onehot_from_family(bufs["family"][1:], n, 3, part, block_stride=bs, n_depths=D - 1)
+            assert torch.equal(part.view(D - 1, 13 * bs, 20, 24), one[1:])
+        # parent block == the oracle's parent code, every depth
+        exp = oracle.adi(3, n, D, seed=3, stream=1, want_children=False, threads=4)
+        got = many.view(D, 13, bs, 20, 24)[:, 12, :n].argmax(-1).cpu().numpy()
+        assert (got.transpose(1, 0, 2) == exp["parent_code"]).all()
+        # targets: random values laid out as the net's output [D][13][bs]
+        g = torch.Generator(device="cuda").manual_seed(n)
+        v = torch.randn(D * 13 * bs, generator=g, device="cuda")
+        wgt = torch.tensor([float(d + 1) ** -0.5 for d in range(D)], dtype=torch.float64, device="cuda")
+        tv = torch.zeros((n + 3, D + 2), dtype=torch.float32, device="cuda")
+        tp = torch.zeros((n + 3, D + 2), dtype=torch.int32, device="cuda")
+        er = torch.zeros((n + 3, D + 2), dtype=torch.float64, device="cuda")
+        ops.adi_targets_depths(v, 13 * bs, bs, bufs["child_solved"], v[12 * bs:], 13 * bs, wgt, n, D, 3, tv[3:, 1:], tp[3:, 1:], er[3:, 1:])
+        vv = v.view(D, 13, bs)
+        for d in range(D):
+            cv = torch.zeros((12, bufs["child_solved"].shape[-1]), dtype=torch.float32, device="cuda")
+            cv[:, :n] = vv[d, :12, :n]
+            a, b_, c = ops.adi_targets(cv, bufs["child_solved"][d], n, 3, vv[d, 12, :n].contiguous(), torch.full((n,), float(wgt[d]), dtype=torch.float64, device="cuda"))
+            assert torch.equal(tv[3:3 + n, 1 + d], a) and torch.equal(tp[3:3 + n, 1 + d], b_) and torch.equal(er[3:3 + n, 1 + d], c)
+        assert float(tv[:3].abs().sum()) == 0 and float(tv[:, 0].abs().sum()) == 0 and float(tv[:, D + 1].abs().sum()) == 0   # nothing outside the view
+    with pytest.raises(L.RubikHipError):
+        ops.onehot_from_family(bufs["family"], n, 3, many[:100], block_stride=bs, n_depths=D)
+    with pytest.raises(L.RubikHipError):
+        ops.adi_targets_depths(v[:10], 13 * bs, bs, bufs["child_solved"], v[12 * bs:], 13 * bs, wgt, n, D, 3, tv[3:, 1:], tp[3:, 1:], er[3:, 1:])
+
+
+def _numpy_legacy(seeds, ks, A):
+    out = []
+    saved = np.random.get_state()
+    try:
+        for s, k in zip(seeds, ks):
+            np.random.seed(int(s))
+            out.append(np.random.randint(A, size=int(k)))
+    finally:
+        np.random.set_state(saved)
+    return out
+
+
+@pytest.mark.parametrize("cs", [3, 2])
+def test_legacy_generator_forms_agree_with_numpy(ops, L, cs):
+    """reset(seed, k)'s draws (cube_env.py:62-65) from both device forms of numpy's legacy generator: the LDS form (lazy twist), the
+    streaming form at its default limit, and the streaming form with a limit so low that most waves overflow and are redone by the
+    fix-up launch -- every byte equal to numpy's, pad rows = the no-op."""
+    A = 12 if cs == 3 else 6
+    rng = np.random.default_rng(cs)
+    n = 1500
+    seeds = rng.integers(0, 2 ** 32, n, dtype=np.uint64)
+    seeds[:4] = (0, 1, 2 ** 32 - 1, 10)
+    for ks, label in ((np.full(n, 30), "k=30"), (rng.integers(0, 61, n), "mixed 0..60"), (np.r_[rng.integers(1, 40, n - 3), [170, 171, 200]], "up to 200")):
+        want = _numpy_legacy(seeds, ks, A)
+        kmax = int(ks.max())
+        uniform = int(ks[0]) if (ks == ks[0]).all() else None
+        for variant in (0, 1, 2, 2 + 16 * 40, 2 + 16 * 7, 2 + 16 * 227):
+            buf, kk = ops.legacy_scramble_actions(torch.from_numpy(seeds.astype(np.int64)), cs, uniform if uniform is not None else ks.tolist(), device="cuda", variant=variant)
+            got = buf.cpu().numpy()
+            assert kk == kmax
+            for i in range(n):
+                assert (got[:ks[i], i] == want[i]).all(), (label, variant, i)
+                assert (got[ks[i]:kmax, i] == A).all(), (label, variant, i)
+    # more than one generation (624 outputs) and the k = 1000 scramble of test.py:279: the LDS form, chosen by the default rule
+    ks = np.array([1000, 700, 469, 468, 5])
+    want = _numpy_legacy(seeds[:5], ks, A)
+    for variant in (0, 1):
+        buf, _ = ops.legacy_scramble_actions(torch.from_numpy(seeds[:5].astype(np.int64)), cs, ks.tolist(), device="cuda", variant=variant)
+        got = buf.cpu().numpy()
+        for i in range(5):
+            assert (got[:ks[i], i] == want[i]).all() and (got[ks[i]:, i] == A).all(), (variant, i)
+    for bad in (3, 2 + 16 * 228, -1, 1 + 16):
+        with pytest.raises(L.RubikHipError):
+            ops.legacy_scramble_actions(torch.arange(4), cs, 3, device="cuda", variant=bad)
+
+
+def test_legacy_generator_large_batch_matches_host_function(ops):
+    """2^17 envs x k = 30 on the default route (streaming + fix-up) against vec_env.legacy_scramble_actions (numpy itself)."""
+    from rubiks_cube_solver_amd.vec_env import legacy_scramble_actions
+    n = 1 << 17
+    seeds = np.random.default_rng(1).integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.int64)
+    buf, _ = ops.legacy_scramble_actions(torch.from_numpy(seeds), 3, 30, device="cuda")
+    want = legacy_scramble_actions(seeds[:20000], 30, 12)
+    assert (buf[:, :20000].cpu().numpy().T == want).all()
+    lds, _ = ops.legacy_scramble_actions(torch.from_numpy(seeds), 3, 30, device="cuda", variant=1)
+    assert torch.equal(buf[:, :n], lds[:, :n])
+
+
+def test_workspace_must_not_alias_operands(ops, L):
+    """rc_apply_moves_ws / rc_encode_ws reject a workspace carved out of an operand instead of producing wrong rows."""
+    n = 1 << 17
+    st = ops.alloc_states(n, 3, "cuda")
+    ops.fill_solved(st, n, 3)
+    dst = torch.empty_like(st)
+    acts = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    oh = torch.empty((n, 20, 24), dtype=torch.float32, device="cuda")
+    need = L.lib().rc_workspace_bytes(L.OP_STEP, 3, n, L.FMT_F32)
+    assert need > 0
+    sp = L.stream_ptr(torch.device("cuda"))
+    P = L.ptr
+    L.init(torch.device("cuda", torch.cuda.current_device()))
+    good = torch.empty(need, dtype=torch.uint8, device="cuda")
+    assert L.lib().rc_apply_moves_ws(P(st), P(dst), P(acts), n, st.shape[2], dst.shape[2], 3, None, None, P(oh), L.FMT_F32, 0, P(good), need, sp) == 0
+    for alias in (oh.view(torch.uint8).view(-1)[1024:], st.view(-1), dst.view(-1)[16:]):
+        rc = L.lib().rc_apply_moves_ws(P(st), P(dst), P(acts), n, st.shape[2], dst.shape[2], 3, None, None, P(oh), L.FMT_F32, 0, P(alias), need, sp)
+        assert rc == -1 and b"overlaps" in L.lib().rc_last_error()
+    rc = L.lib().rc_encode_ws(P(st), n, st.shape[2], 3, P(oh), L.FMT_F32, 0, P(oh.view(torch.uint8).view(-1)[4096:]), need, sp)
+    assert rc == -1 and b"overlaps" in L.lib().rc_last_error()
+    torch.cuda.synchronize()
+
+
+def test_facade_release_from_another_thread(L):
+    """the alias cache of the batch-1 entry points is process-wide, so a release issued by whichever thread runs the
+    garbage collector takes effect for the thread that used the buffer."""
+    import threading
+
+    import rubiks_cube_solver_amd as rc
+    env = rc.make_env(torch.device("cpu"), 3)
+    env.step(3)
+    host = env._fast[2]
+    t = threading.Thread(target=lambda: L.lib().rc_facade_release(host))
+    t.start()
+    t.join()
+    s, r, d, _ = env.step(2)                        # re-validated, still correct
+    ref = rc.make_env(torch.device("cpu"), 3)
+    ref.step(3)
+    s2, _, _, _ = ref.step(2)
+    assert (s == s2).all()
+    results = []
+
+    def worker():                                   # a second thread stepping its own env through the shared table
+        e = rc.make_env(torch.device("cpu"), 3)
+        for a in (3, 2):
+            out = e.step(a)
+        results.append(out[0])
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    assert (results[0] == s2).all()
+    env.close()
+    ref.close()

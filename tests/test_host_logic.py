@@ -110,8 +110,9 @@ def test_abi_exports_every_declared_symbol():
     assert len(declared) >= 15
     for name in declared:
         assert hasattr(L, name), name
-    assert L.rc_version() >= 400 and len(declared) == 30 and {"rc_describe_dispatch", "rc_facade_release", "rc_apply_moves_ws", "rc_encode_ws", "rc_workspace_bytes",
-                                                              "rc_adi_generate_family", "rc_family_layout", "rc_onehot_from_family"} <= declared
+    assert L.rc_version() >= 500 and len(declared) == 33 and {"rc_describe_dispatch", "rc_facade_release", "rc_apply_moves_ws", "rc_encode_ws", "rc_workspace_bytes",
+                                                              "rc_adi_generate_family", "rc_family_layout", "rc_onehot_from_family", "rc_onehot_from_family_depths",
+                                                              "rc_adi_targets_depths", "rc_legacy_scramble_actions_ex"} <= declared
     # every rc_* the library exports is declared in the header, and nothing else leaves it
     import subprocess
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
@@ -160,7 +161,7 @@ def test_dispatch_description_and_enodev_without_gpu():
     assert L.describe(L.OP_STEP, 2, 1 << 22, outputs=st).startswith("k_step<Cube2,")
     assert L.describe(L.OP_STEP, 3, 1 << 20, outputs=st, fmt=L.FMT_BF16).startswith("k_step_dense<Cube3,bf16,move,store,TILE=64> grid=16384")
     assert L.describe(L.OP_STEP, 3, 1 << 20, outputs=st, fmt=L.FMT_U8).startswith("k_step_dense<Cube3,u8,move,store,TILE=256> grid=4096")
-    assert L.describe(L.OP_STEP, 3, 1 << 20, outputs=st, fmt=L.FMT_BF16, variant=300000).startswith("k_step_dense<Cube3,bf16,move,store,TILE=256> grid=4096")
+    assert L.describe(L.OP_STEP, 3, 1 << 20, outputs=st, fmt=L.FMT_BF16, variant=200000).startswith("k_step_dense<Cube3,bf16,move,store,TILE=256> grid=4096")
     assert "TILE=64" in L.describe(L.OP_STEP, 3, 1 << 20, outputs=st, fmt=L.FMT_BF16, variant=100000)
     assert L.describe(L.OP_STEP, 2, 1 << 20, outputs=st, fmt=L.FMT_BF16).startswith("k_step_dense<Cube2,bf16,move,store,TILE=256>")
     assert L.describe(L.OP_STEP, 3, 4096, outputs=0, fmt=L.FMT_F32).startswith("k_step_dense<Cube3,f32,encode,TILE=64>")
@@ -248,26 +249,85 @@ def test_family_layout_table():
                     assert rows[a, p_] == rows[A, p_], (cs, a, p_)
 
 
-def test_product_code_never_injects_a_backend():
-    """`CubeEnv(_backend=...)` is the seam tests/fake_backend.py uses to run the facade's host logic on CPU; it is also the one
-    seam through which the facade could run on something other than the HIP library.  No product file (the package, bench.py,
-    __graft_entry__.py, tools/) passes it: `make_env` and every `CubeEnv(...)` call construct the real VecCubeEnv."""
-    pat = re.compile(r"\b_backend\s*=")
-    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
-    for d in ("rubiks-cube-solver_amd", "rubiks_cube_solver_amd", "tools"):
-        for dp, _, fs in os.walk(os.path.join(ROOT, d)):
-            files += [os.path.join(dp, f) for f in fs if f.endswith(".py")]
-    hits = []
-    for f in files:
-        for i, line in enumerate(open(f).read().splitlines(), 1):
-            if pat.search(line):
-                hits.append((os.path.relpath(f, ROOT), i, line.strip()))
-    # the only places the name is assigned: CubeEnv.__init__'s own parameter default and its construction of the real backend
-    allowed = {"rubiks-cube-solver_amd/cube_env.py"}
-    assert {h[0] for h in hits} <= allowed, hits
-    src = open(os.path.join(ROOT, "rubiks-cube-solver_amd", "cube_env.py")).read()
-    assert "return CubeEnv(device=device, cube_size=cube_size)" in src               # make_env (env.py:3-5): no backend argument
-    assert src.count("_backend=None") == 1 and "_backend = VecCubeEnv(" in src
+def _variant_macros():
+    """RC_VARIANT_* of include/rubikhip.h as Python callables (the bodies are plain integer arithmetic)."""
+    src = open(os.path.join(ROOT, "include", "rubikhip.h")).read()
+    out = {}
+    for name, arg, body in re.findall(r"^#define (RC_VARIANT_\w+)\((\w+)\) (.+?)\s*(?:/\*.*)?$", src, re.M):
+        out[name] = eval(f"lambda {arg}: {body}")
+    for name, body in re.findall(r"^#define (RC_VARIANT_\w+) (\d+)\s", src, re.M):
+        out[name] = int(body)
+    return out
+
+
+def test_variant_macros_round_trip_through_describe_dispatch():
+    """Every RC_VARIANT_* macro of the header, through rc_describe_dispatch (no GPU needed): the field shows up in the dispatch of ITS
+    entry point and is rejected by every entry point whose group does not define it."""
+    from rubiks_cube_solver_amd import _lib as L
+    M = _variant_macros()
+    assert set(M) == {"RC_VARIANT_STEP_PACK", "RC_VARIANT_STEP_POLICY", "RC_VARIANT_STEP_DENSE_TILE", "RC_VARIANT_EXPAND_PACK", "RC_VARIANT_EXPAND_STREAM",
+                      "RC_VARIANT_EXPAND_PARTS", "RC_VARIANT_ADI_PACK", "RC_VARIANT_ADI_PARTS", "RC_VARIANT_ADI_SEGS", "RC_VARIANT_DENSE_FORM",
+                      "RC_VARIANT_DENSE_WIDE_GROUPS16", "RC_VARIANT_DENSE_WIDE_SKEW", "RC_VARIANT_DENSE_FRONTS", "RC_VARIANT_DENSE_FRONT_FETCH",
+                      "RC_VARIANT_LEGACY_LDS", "RC_VARIANT_LEGACY_STREAM"}
+    st = L.OUT_STATES | L.OUT_DONE
+    n = 1 << 20
+    step = lambda v, **kw: L.describe(L.OP_STEP, 3, n, outputs=st, variant=v, **kw)
+    expand = lambda v: L.describe(L.OP_EXPAND, 3, n, outputs=L.OUT_STATES | L.OUT_FLAGS, variant=v)
+    adi = lambda v: L.describe(L.OP_ADI, 3, 100000, 30, outputs=L.OUT_CODE | L.OUT_FLAGS, variant=v)
+    dense = lambda v, fmt=L.FMT_BF16: L.describe(L.OP_CODE_TO_DENSE, 3, n, fmt=fmt, variant=v)
+    for v in (1, 2):
+        assert f"V={v}," in step(M["RC_VARIANT_STEP_PACK"](v)) and f"V={v}" in expand(M["RC_VARIANT_EXPAND_PACK"](v) + M["RC_VARIANT_EXPAND_STREAM"](8))
+        assert f"V={v}," in adi(M["RC_VARIANT_ADI_PACK"](v))
+    for p, pol in ((1, 2), (2, 0), (3, 1), (4, 3)):
+        assert f"POL={pol}>" in step(M["RC_VARIANT_STEP_POLICY"](p))
+    assert "TILE=64>" in step(M["RC_VARIANT_STEP_DENSE_TILE"](1), fmt=L.FMT_BF16) and "TILE=256>" in step(M["RC_VARIANT_STEP_DENSE_TILE"](2), fmt=L.FMT_BF16)
+    for h, waves in ((1, 128), (5, 512), (7, 1024)):
+        assert expand(M["RC_VARIANT_EXPAND_STREAM"](h)).startswith(f"k_expand_stream<Cube3> grid={waves}")
+    assert expand(M["RC_VARIANT_EXPAND_STREAM"](8)).startswith("k_expand<")
+    for parts in (1, 3, 12):
+        assert f"parts={parts} " in expand(M["RC_VARIANT_EXPAND_PARTS"](parts)) and f"parts={parts} " in adi(M["RC_VARIANT_ADI_PARTS"](parts) + M["RC_VARIANT_ADI_PACK"](1))
+    for segs in (1, 4, 16):
+        assert f"segs={segs} " in adi(M["RC_VARIANT_ADI_SEGS"](segs))
+    assert "k_code_to_dense<Cube3,bf16,TILE=64>" in dense(M["RC_VARIANT_DENSE_FORM"](1)) and "TILE=256>" in dense(M["RC_VARIANT_DENSE_FORM"](2))
+    assert dense(M["RC_VARIANT_DENSE_FORM"](3) + M["RC_VARIANT_DENSE_WIDE_GROUPS16"](4) + M["RC_VARIANT_DENSE_WIDE_SKEW"](3)).startswith("k_code_to_dense_wide<Cube3,bf16> tiles_per_group=")
+    assert "grid=64 " in dense(M["RC_VARIANT_DENSE_FORM"](3) + M["RC_VARIANT_DENSE_WIDE_GROUPS16"](4))
+    for f in (1, 2, 4):
+        assert f"k_code_to_dense_front<Cube3,bf16,F={f}," in dense(M["RC_VARIANT_DENSE_FORM"](4) + M["RC_VARIANT_DENSE_FRONTS"](f))
+    assert ",gather>" in dense(M["RC_VARIANT_DENSE_FRONT_FETCH"](3)) and ",lds>" in dense(M["RC_VARIANT_DENSE_FRONT_FETCH"](4), L.FMT_F32)
+    assert " xcd " not in dense(M["RC_VARIANT_DENSE_FRONT_FETCH"](2)) and " xcd " in dense(0)
+    # fields of another group, and digits no group defines, are rejected -- by the describing call here, by the launchers on the GPU
+    wrong = [(step, M["RC_VARIANT_ADI_SEGS"](2)), (step, M["RC_VARIANT_EXPAND_STREAM"](3)), (step, M["RC_VARIANT_EXPAND_PARTS"](2)), (step, M["RC_VARIANT_DENSE_FORM"](3)),
+             (step, M["RC_VARIANT_DENSE_FORM"](4)), (step, 3), (step, M["RC_VARIANT_STEP_POLICY"](5)), (expand, M["RC_VARIANT_STEP_POLICY"](1)),
+             (expand, M["RC_VARIANT_EXPAND_STREAM"](9)), (expand, M["RC_VARIANT_EXPAND_PARTS"](13)), (expand, M["RC_VARIANT_DENSE_FORM"](1)), (expand, M["RC_VARIANT_ADI_SEGS"](1)),
+             (adi, M["RC_VARIANT_STEP_POLICY"](2)), (adi, M["RC_VARIANT_EXPAND_STREAM"](1)), (adi, M["RC_VARIANT_ADI_SEGS"](17)), (adi, M["RC_VARIANT_ADI_PARTS"](13)),
+             (adi, M["RC_VARIANT_DENSE_FORM"](2)), (dense, M["RC_VARIANT_ADI_SEGS"](1)), (dense, M["RC_VARIANT_EXPAND_STREAM"](1)), (dense, M["RC_VARIANT_DENSE_FORM"](5)),
+             (dense, M["RC_VARIANT_DENSE_FORM"](4) + 3), (dense, M["RC_VARIANT_DENSE_FORM"](4) + M["RC_VARIANT_DENSE_FRONT_FETCH"](1)),
+             (dense, M["RC_VARIANT_DENSE_FORM"](1) + 1), (dense, M["RC_VARIANT_DENSE_FORM"](3) + 1), (dense, M["RC_VARIANT_DENSE_FORM"](4) + M["RC_VARIANT_DENSE_WIDE_GROUPS16"](2)),
+             (step, -1), (step, 100000000), (adi, 1 << 30)]
+    for fn, v in wrong:
+        with pytest.raises(L.RubikHipError, match="variant"):
+            fn(v)
+    # 2x2x2: six actions bound the parts field
+    assert "parts=6 " in L.describe(L.OP_EXPAND, 2, n, outputs=L.OUT_STATES, variant=M["RC_VARIANT_EXPAND_PARTS"](6))
+    with pytest.raises(L.RubikHipError, match="variant"):
+        L.describe(L.OP_EXPAND, 2, n, outputs=L.OUT_STATES, variant=M["RC_VARIANT_EXPAND_PARTS"](7))
+    assert M["RC_VARIANT_LEGACY_LDS"] == 1 and M["RC_VARIANT_LEGACY_STREAM"](0) == 2 and M["RC_VARIANT_LEGACY_STREAM"](40) == 642
+
+
+def test_cube_env_has_no_backend_parameter():
+    """The facade has ONE implementation: CubeEnv takes no backend argument and carries no branch for one (round 4's `_backend=`
+    seam is gone); the CPU tests below subclass it in tests/fake_backend.py and override its device hooks instead."""
+    import inspect
+    from rubiks_cube_solver_amd.cube_env import CubeEnv, make_env
+    assert list(inspect.signature(CubeEnv.__init__).parameters) == ["self", "device", "cube_size", "compute_device"]
+    assert list(inspect.signature(make_env).parameters) == ["device", "cube_size"]            # env.py:3-5
+    with pytest.raises(TypeError):
+        CubeEnv(torch.device("cpu"), cube_size=3, _backend=object())
+    for dp, _, fs in os.walk(os.path.join(ROOT, "rubiks-cube-solver_amd")):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"\b_backend\b", src) and "test-only" not in src.lower(), f
 
 
 def test_tile_helpers():
@@ -284,9 +344,8 @@ def test_tile_helpers():
 
 # ---------------------------------------------------- CubeEnv host semantics (oracle-backed, CPU)
 def _env(cs):
-    from rubiks_cube_solver_amd.cube_env import CubeEnv
-    from tests.fake_backend import OracleBackend
-    return CubeEnv(torch.device("cpu"), cube_size=cs, _backend=OracleBackend(cs))
+    from tests.fake_backend import HostLogicCubeEnv
+    return HostLogicCubeEnv(torch.device("cpu"), cube_size=cs)
 
 
 def test_cube_env_surface_and_types(golden):
@@ -315,9 +374,9 @@ def test_cube_env_surface_and_types(golden):
     assert s2.shape == (7, 21) and s2.dtype == np.float64 and e2.state_dim == [7, 21] and e2.action_dim == 6
     with pytest.raises(IndexError):
         e2.step(6)
-    from rubiks_cube_solver_amd.cube_env import CubeEnv
+    from tests.fake_backend import HostLogicCubeEnv
     with pytest.raises(NotImplementedError):
-        CubeEnv(torch.device("cpu"), cube_size=4, _backend=object())
+        HostLogicCubeEnv(torch.device("cpu"), cube_size=4)
 
 
 def test_cube_env_reset_matches_reference_rng(golden):

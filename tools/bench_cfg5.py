@@ -45,20 +45,18 @@ def timeit(fn, iters=200, warm=20):
 
 
 @torch.no_grad()
-def run(short=False):
-    """-> dict of microsecond timings.  short: fewer repetitions and no lockstep-search legs (bench.py's default line)."""
-    global timeit
-    if short:
-        full_timeit = timeit
-        timeit = lambda fn, iters=60, warm=10: full_timeit(fn, iters, warm)
-    try:
-        return _run(short)
-    finally:
-        if short:
-            timeit = full_timeit
+def run(short=False, iters=None, sims=20):
+    """-> dict of microsecond timings.  short: fewer repetitions (bench.py's default line); the lockstep-search legs always run.
+    Legs: the kernels of one MCTS step on 4096 leaves (expansion, dense encode, net forward) one by one, as the serial sequence the
+    product launches (eager and as a hipGraph), ONE two-stream variant for BASELINE config 5's wording ("interleaved with the value-net
+    forward": it loses at this size and the product does not use it), then the product's lockstep search: device step, device step +
+    upload + packed download, and whole simulations split into select / device + transfers / update."""
+    import time
 
-
-def _run(short):
+    import numpy as np
+    iters = iters or (60 if short else 200)
+    warm = 10 if short else 20
+    T = lambda fn: timeit(fn, iters, warm)
     n, cs, dev = 4096, 3, torch.device("cuda")
     model = DeepCubeStandIn().to(dev).eval()
     leaves = ops.alloc_states(n, cs, dev)
@@ -66,7 +64,6 @@ def _run(short):
     ops.scramble(leaves, n, cs, 20, seed=7)
     ex = ops.expand_buffers(n, cs, dev, children=True, codes=True)
     pitch = ex["children"].shape[-1]
-    code = ops.alloc_code(n, cs, dev)
     onehot = torch.empty((n, 20, 24), dtype=torch.float32, device=dev)
     side = torch.cuda.Stream(dev)
 
@@ -94,13 +91,15 @@ def _run(short):
 
     res = {
         "leaves": n, "children_per_step": n * 12,
-        "expand_stickers_codes_flags_us": timeit(expand),
-        "expand_codes_flags_us": timeit(expand_flags_codes),
-        "encode_dense_f32_us": timeit(encode),
-        "forward_us": timeit(forward),
-        "serial_step_us": timeit(serial),
-        "overlapped_step_us": timeit(overlapped),
+        "expand_stickers_codes_flags_us": T(expand),
+        "expand_codes_flags_us": T(expand_flags_codes),
+        "encode_dense_f32_us": T(encode),
+        "forward_us": T(forward),
+        "serial_step_us": T(serial),
+        "two_stream_step_us": T(overlapped),
     }
+    res["two_stream_note"] = ("expansion on a side stream next to encode + forward: the two cross-stream dependencies cost more than the ~7 us of expansion they "
+                              "could hide; BatchedMCTS runs everything on one stream")
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream(dev)
     s.wait_stream(torch.cuda.current_stream())
@@ -111,25 +110,11 @@ def _run(short):
     try:
         with torch.cuda.graph(g):
             serial()
-        res["hipgraph_serial_step_us"] = timeit(g.replay)
+        res["hipgraph_serial_step_us"] = T(g.replay)
     except Exception as e:  # capture of foreign launches may be refused by the runtime
         res["hipgraph_serial_step_us"] = None
         res["hipgraph_error"] = str(e)[:200]
-    try:                                     # fork/join inside one graph: expansion branch || encode + forward branch
-        g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2):
-            overlapped()
-        res["hipgraph_overlapped_step_us"] = timeit(g2.replay)
-    except Exception as e:
-        res["hipgraph_overlapped_step_us"] = None
-        res["hipgraph_overlap_error"] = str(e)[:200]
-    hidden = res["serial_step_us"] - res["overlapped_step_us"]
-    res["overlap_hidden_us"] = hidden
-    res["overlap_fraction_of_expand"] = hidden / res["expand_stickers_codes_flags_us"]
-    if short:
-        return res
-    # the product's lockstep search: device part of one simulation (replay 8 moves + expand + one-hot + forward)
-    import numpy as np
+    # the product's lockstep search: device part of one simulation (replay 8 moves + expand + one-hot + forward + result packing)
     from rubiks_cube_solver_amd.mcts_batched import BatchedMCTS
     paths = np.random.default_rng(0).integers(0, 12, (n, 8), dtype=np.uint8)
     for name, kw in (("eager", {}), ("hipgraph", {"graph": True})):
@@ -137,34 +122,45 @@ def _run(short):
         bm.leaves_step(paths)
         bm.leaves_step(paths)
         torch.cuda.synchronize()
-        if kw:
-            gobj = bm._graphs[8][0]
-            res[f"batched_mcts_device_step_{name}_us"] = timeit(gobj.replay)
-        else:
-            res[f"batched_mcts_device_step_{name}_us"] = timeit(lambda: bm._device_step(8))
-        import time
+        res[f"batched_mcts_device_step_{name}_us"] = T(bm._graphs[8].replay) if kw else T(lambda: bm._device_step(8))
         t0 = time.perf_counter()
-        for _ in range(20):
-            bm.leaves_step(paths)
-        res[f"batched_mcts_leaves_step_with_d2h_{name}_us"] = (time.perf_counter() - t0) / 20 * 1e6
-    # whole simulations of the lockstep search (host trees in librubiktree.so + the device step + downloads)
+        for _ in range(sims):
+            bm.leaves_step(paths, copy=False)
+        res[f"batched_mcts_leaves_step_with_d2h_{name}_us"] = (time.perf_counter() - t0) / sims * 1e6
+    res["batched_mcts_transfers_us"] = res["batched_mcts_leaves_step_with_d2h_hipgraph_us"] - res["batched_mcts_device_step_hipgraph_us"]
+    # whole simulations of the lockstep search (host trees in librubiktree.so + the device step + transfers), split per phase
     import random
     bm = BatchedMCTS(model, leaves, n, cs, graph=True, rngs=[random.Random(r) for r in range(n)])
     for _ in range(10):
         bm.simulate()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(20):
-        bm.simulate()
-    torch.cuda.synchronize()
-    res["batched_mcts_simulate_native_tree_ms"] = (time.perf_counter() - t0) / 20 * 1e3
-    res["batched_mcts_note"] = "simulations 11-30 of 4096 roots, per-root generators, hipGraph device step; the pure-Python tree needs 100-500 ms per simulation"
+    split = {"select": 0.0, "device_and_transfers": 0.0, "update": 0.0}
+    t_all = time.perf_counter()
+    for _ in range(sims):
+        t0 = time.perf_counter()
+        p = bm.native.select()
+        t1 = time.perf_counter()
+        out = bm.leaves_step(p, copy=False)
+        t2 = time.perf_counter()
+        bm.native.update(*out)
+        t3 = time.perf_counter()
+        split["select"] += t1 - t0
+        split["device_and_transfers"] += t2 - t1
+        split["update"] += t3 - t2
+    total = time.perf_counter() - t_all
+    res["batched_mcts_simulate_native_tree_ms"] = total / sims * 1e3
+    res["batched_mcts_simulate_split_us"] = {k: v / sims * 1e6 for k, v in split.items()}
+    res["batched_mcts_note"] = (f"simulations 11-{10 + sims} of 4096 roots, per-root generators, hipGraph device step, one packed download; select / update = "
+                                "librubiktree.so (C++ / OpenMP on this job's CPU share); the pure-Python tree needs 100-500 ms per simulation")
     return res
 
 
+def rounded(res):
+    return {k: (round(v, 2) if isinstance(v, float) else {a: round(b, 2) for a, b in v.items()} if isinstance(v, dict) else v) for k, v in res.items()}
+
+
 def main():
-    res = run()
-    print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in res.items()}))
+    print(json.dumps(rounded(run())))
 
 
 if __name__ == "__main__":

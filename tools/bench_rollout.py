@@ -30,13 +30,18 @@ def run(n, T, graph, model):
     return {"seconds": round(dt, 4), "us_per_timestep": round(dt / steps * 1e6, 1), "cube_steps_per_s": round(n * steps / dt, 1)}
 
 
-def main():
-    model = DeepCubeStandIn().cuda().eval()
+def run_all(T=200, model=None):
+    """n = 300 is train.py:167-198's validation batch (30 scramble depths x 10 cubes); 65536 a large batch."""
+    model = model or DeepCubeStandIn().cuda().eval()
     out = {}
     for n in (300, 65536):
         for graph in (False, True):
-            out[f"n{n}_{'hipgraph' if graph else 'eager'}"] = run(n, 200, graph, model)
-    print(json.dumps(out))
+            out[f"n{n}_{'hipgraph' if graph else 'eager'}"] = run(n, T, graph, model)
+    return out
+
+
+def main():
+    print(json.dumps(run_all()))
 
 
 if __name__ == "__main__":

@@ -283,6 +283,15 @@ def other_configs(torch, ops, _lib, dev, acts):
     rec("ADI 100k x 30 family", "ADI 100k x 30 as adi_samples launches it: the 51-byte FAMILY record (the shared look-ups behind the 13 codes) + child flags + actions, "
         "no stickers", D(_lib.OP_ADI, CUBE, W, DEPTH, outputs=_lib.OUT_FAMILY | FLAGS), W * DEPTH, "walk-depths", 51 + 12 + 1, t,
         f"output tiles of {pt} walks; 64 B per (walk, depth) against 327 B with the picked codes: the launch is VALU-bound, read the time, not the fraction")
+    # the family record -> the [depth][13][walks] dense input of the value net (rc_onehot_from_family_depths): what AdiPlan launches per group of depths
+    for wn, gd, dt, name, esz in ((43008, 1, torch.float32, "f32", 4), (20000, 2, torch.float32, "f32", 4), (43008, 2, torch.bfloat16, "bf16", 2)):
+        bs = -(-wn // 8) * 8
+        blocks = torch.empty((gd * 13 * bs, 20, 24), dtype=dt, device=dev)
+        fam = ab["family"][:gd, :-(-wn // pt)].contiguous()
+        t = timed(lambda: ops.onehot_from_family(fam, wn, CUBE, blocks, block_stride=bs, n_depths=gd), 10, 3)
+        rec(f"ADI dense blocks {name} {wn}x{gd}", f"ADI family record -> dense {name} one-hot blocks [depth][13][walks] of {wn} walks x {gd} depth(s): the value net's input, one launch "
+            "(rc_onehot_from_family_depths)", D(_lib.OP_FAMILY_TO_DENSE, CUBE, wn, gd, fmt=_lib.fmt_of(dt)), wn * gd, "walk-depths", 51 + 13 * 480 * esz, t)
+        del blocks, fam
     del ab
     torch.cuda.empty_cache()
     out = {"records": recs, "hbm_only_frac": hbm_only["roofline"]["frac"]}
@@ -401,7 +410,7 @@ def per_config_summary(configs):
     """Compact per-config table for the `roofline` object: name, kernel, launch time, algorithmic bytes per launch, fraction of the
     8 TB/s peak -- frac = bytes / (launch_us * 1e-6) / 8e12, recomputable from the row alone."""
     import re
-    return [{"name": r["short"], "kernel": re.sub(r" (grid|block|tiles_per_group|cubes_per_pass)=\d+", "", r["kernel"]), "launch_us": round(r["launch_us"], 2),
+    return [{"name": r["short"], "kernel": re.sub(r" (grid|block|tiles_per_group|cubes_per_pass)=\d+(x\d+)?", "", r["kernel"]), "launch_us": round(r["launch_us"], 2),
              "bytes": r["roofline"]["algorithmic_bytes_per_launch"], "frac": round(r["roofline"]["frac"], 4)}
             for r in configs["records"]]
 

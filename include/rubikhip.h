@@ -150,6 +150,11 @@ int rc_facade_expand(const uint8_t *st, int64_t pitch, int cube_size, uint8_t *h
  * buffer, from ANY thread (NULL drops everything cached); CubeEnv.close() / garbage collection does. */
 int rc_facade_release(const uint8_t *host_out);
 
+/* Device address of HOST-MAPPED pinned memory (hipHostMalloc / hipHostRegister / torch pin_memory), for callers that let a kernel
+ * read a small input straight from host memory instead of uploading it first: e.g. the action paths of a lockstep tree search, written
+ * by the host trees and replayed by rc_scramble(actions_in = the alias) -- one H2D copy less per simulation.  RC_EINVAL for other memory. */
+int rc_host_alias(const void *host, void **device_alias);
+
 /* `depth` moves applied in place to every cube: the scramble loop of CubeEnv.reset
  * (cube_env.py:65-67) for n_cubes cubes at once.  actions_in[d * act_pitch + n] replays given
  * moves (e.g. the host's legacy-numpy draws, for bit-exact reset(seed)); NULL draws them on
@@ -158,6 +163,20 @@ int rc_facade_release(const uint8_t *host_out);
 int rc_scramble(uint8_t *st, int64_t n_cubes, int64_t pitch, int cube_size, int depth, uint64_t seed,
                 uint64_t stream_id, int64_t walk_offset, const uint8_t *actions_in, uint8_t *actions_out,
                 int64_t act_pitch, uint8_t *done, float *reward, void *stream);
+
+/* rc_scramble that reads the start states from `src` (same layout and pitch as st) and leaves them untouched: st = src moved.  The
+ * lockstep tree search replays every simulation's descents from its root states this way (mcts.py:37,80: one deepcopy + one env.step
+ * per tree level there).  depth == 0 copies. */
+int rc_scramble_from(const uint8_t *src, uint8_t *st, int64_t n_cubes, int64_t pitch, int cube_size, int depth,
+                     uint64_t seed, uint64_t stream_id, int64_t walk_offset, const uint8_t *actions_in,
+                     uint8_t *actions_out, int64_t act_pitch, uint8_t *done, float *reward, void *stream);
+
+/* One record per root for the host trees of a lockstep search (include/rubiktree.h rc_tree_update; mcts.py:96-101 keeps the same three
+ * things per expanded node): from the leaves' codes (RC_FMT_CODE layout, [tile][SLOTS][pitch]) and the outputs of rc_expand_children
+ * with pitch_out = pitch (child_code [A][tiles][SLOTS][pitch], child_solved [A][tiles * pitch]) to
+ * leaf_out [n][SLOTS], child_out [n][A][SLOTS], solved_out [n][A], contiguous. */
+int rc_search_pack(const uint8_t *leaf_code, const uint8_t *child_code, const uint8_t *child_solved, int64_t n_cubes,
+                   int64_t pitch, int cube_size, uint8_t *leaf_out, uint8_t *child_out, uint8_t *solved_out, void *stream);
 
 /* The scramble draws of CubeEnv.reset(seed, k) (cube_env.py:62-68) for n envs at once, bit for bit:
  * np.random.seed(seeds[i]); np.random.randint(action_dim, size=k_i) of numpy's LEGACY generator
@@ -275,7 +294,7 @@ int rc_read_status(uint32_t *status, void *stream);
 
 /* Which kernel instantiation and launch geometry a call WOULD use, as text (e.g. "k_step<Cube3,V=2,move,store,POL=1>
  * grid=8192 block=64"), decided by the same host functions the launchers call: benchmarks label their records with it.
- *   op       RC_OP_STEP (rc_apply_moves / rc_is_solved / rc_encode), RC_OP_EXPAND, RC_OP_ADI, RC_OP_CODE_TO_DENSE
+ *   op       RC_OP_STEP (rc_apply_moves / rc_is_solved / rc_encode), RC_OP_EXPAND, RC_OP_ADI, RC_OP_CODE_TO_DENSE, RC_OP_FAMILY_TO_DENSE
  *   n        cubes / parents / walks;  depth: RC_OP_ADI only
  *   outputs  RC_OUT_* bits: STATES = the out buffer of a step (move + store) or the children stickers, CODE = compact codes,
  *            FLAGS = child_solved, REWARD / DONE = the step's reward / done arrays, INPLACE = out aliases in (step)
@@ -285,6 +304,7 @@ int rc_read_status(uint32_t *status, void *stream);
 #define RC_OP_EXPAND 2
 #define RC_OP_ADI 3
 #define RC_OP_CODE_TO_DENSE 4
+#define RC_OP_FAMILY_TO_DENSE 5 /* rc_onehot_from_family_depths: n = walks, depth = depths per launch, fmt = the dense format; variant must be 0 */
 #define RC_OUT_STATES 1u
 #define RC_OUT_CODE 2u
 #define RC_OUT_FLAGS 4u

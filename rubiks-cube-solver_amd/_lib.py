@@ -64,11 +64,14 @@ def _declare(L):
     L.rc_read_status.argtypes = [vp, vp]
     L.rc_describe_dispatch.argtypes = [i32, i32, i64, i32, ctypes.c_uint32, i32, i32, ctypes.c_char_p, i32]
     L.rc_facade_release.argtypes = [vp]
+    L.rc_host_alias.argtypes = [vp, vp]
+    L.rc_scramble_from.argtypes = [vp, vp, i64, i64, i32, i32, u64, u64, i64, vp, vp, i64, vp, vp, vp]
+    L.rc_search_pack.argtypes = [vp, vp, vp, i64, i64, i32, vp, vp, vp, vp]
     for name in ("rc_init", "rc_get_tables", "rc_fill_solved", "rc_apply_moves", "rc_apply_moves_ex", "rc_facade_step", "rc_facade_steps", "rc_facade_expand", "rc_scramble",
                  "rc_legacy_scramble_actions", "rc_is_solved", "rc_encode", "rc_onehot_from_code", "rc_expand_children",
                  "rc_expand_children_ex", "rc_adi_generate", "rc_adi_generate_ex", "rc_adi_targets", "rc_read_status",
                  "rc_describe_dispatch", "rc_facade_release", "rc_onehot_from_code_ex", "rc_apply_moves_ws", "rc_encode_ws", "rc_adi_generate_family", "rc_family_layout",
-                 "rc_onehot_from_family", "rc_adi_targets_depths", "rc_onehot_from_family_depths", "rc_legacy_scramble_actions_ex"):
+                 "rc_onehot_from_family", "rc_adi_targets_depths", "rc_onehot_from_family_depths", "rc_legacy_scramble_actions_ex", "rc_host_alias", "rc_scramble_from", "rc_search_pack"):
         getattr(L, name).restype = i32
 
 
@@ -128,6 +131,15 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def host_alias(t):
+    """Device address of a pinned (host-mapped) CPU tensor, as a void*: kernels may read it in place (rc_host_alias)."""
+    if t.is_cuda or not t.is_pinned():
+        raise RubikHipError("host_alias: need a pinned CPU tensor")
+    out = ctypes.c_void_p(0)
+    check(lib().rc_host_alias(ctypes.c_void_p(t.data_ptr()), ctypes.byref(out)))
+    return out
+
+
 def pitch_for(n: int, align: int = 256) -> int:
     """Row pitch: >= n, multiple of `align` bytes (256 keeps every row segment line-aligned)."""
     return max(align, (n + align - 1) // align * align)
@@ -150,7 +162,7 @@ def read_status(device=None) -> int:
     return out.value
 
 
-OP_STEP, OP_EXPAND, OP_ADI, OP_CODE_TO_DENSE = 1, 2, 3, 4
+OP_STEP, OP_EXPAND, OP_ADI, OP_CODE_TO_DENSE, OP_FAMILY_TO_DENSE = 1, 2, 3, 4, 5
 OUT_STATES, OUT_CODE, OUT_FLAGS, OUT_REWARD, OUT_INPLACE, OUT_DONE, OUT_WORKSPACE, OUT_FAMILY = 1, 2, 4, 8, 16, 32, 64, 128
 
 

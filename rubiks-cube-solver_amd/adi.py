@@ -140,10 +140,11 @@ class AdiPlan:
         if wc > full * pitch:
             sc[w0 + full * pitch:w0 + wc].copy_(src[full, :wc - full * pitch])
         self.out["actions"][w0:w0 + wc].copy_(bufs["actions_out"][:, :wc].t())
-        if self.want_state_dense:
-            sd = torch.empty((D * p, self.R, self.C), dtype=torch.uint8, device=dev)
-            ops.onehot_from_code(pc.reshape(D * tiles, SL, pitch), D * p, cs, sd)
-            self.out["state"][w0:w0 + wc].copy_(sd.view(D, p, self.R, self.C)[:, :wc].permute(1, 0, 2, 3))
+        if self.want_state_dense:                                  # the reference's per-sample dicts only: one launch per depth
+            sd = torch.empty((D, -(-wc // 16) * 16, self.R, self.C), dtype=torch.uint8, device=dev)   # every depth's block 16-byte aligned
+            for d in range(D):
+                ops.onehot_from_code(pc[d], wc, cs, sd[d])
+            self.out["state"][w0:w0 + wc].copy_(sd[:, :wc].permute(1, 0, 2, 3))
 
     @torch.no_grad()
     def run(self, actions=None, seed=0, stream_id=0, walk_offset=0, clone=False):

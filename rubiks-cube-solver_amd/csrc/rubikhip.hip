@@ -341,11 +341,25 @@ __global__ void __launch_bounds__(kWideBlock) k_code_to_dense_wide(const uint8_t
 // (Wave-uniform scalar loads of the rows + a select chain were tried and lost: 0.64 against 0.81, bf16.)
 // FAM: `code` holds FAMILY rows ([tile][NF][pitch], rc_device.h FamilyLayout) and the launch writes A + 1 blocks -- child a's one-hots
 // at dense + a * block_stride cubes, the parent's as block A: global pass = block * passes_per_block + pass; slot r of block a is family
-// row kFamily.row[a][r] (the per-child pick, from a 260-byte table in constant memory).  Several DEPTHS of one ADI launch go in one
-// launch too (fam.nblk = (A + 1) * depths blocks): depth g reads its family record at code + g * fam.src_depth_stride bytes and writes its
-// A + 1 blocks at dense + g * fam.dst_depth_stride cubes, so the whole [depth][A + 1][block_stride] model input of a small batch is one launch.
-__constant__ FamilyLayout<Cube3> c_family3{};
-struct FamilyBlocks { int64_t block_stride, ppb, src_depth_stride, dst_depth_stride; int nblk; };
+// row kFamily.row[a][r] (the per-child pick).  Several DEPTHS of one ADI launch go in one launch too: blockIdx.y = depth * (A + 1) + block;
+// depth g reads its family record at code + g * fam.src_depth_stride bytes and writes its A + 1 blocks at dense + g * fam.dst_depth_stride
+// cubes, so the whole [depth][A + 1][block_stride] model input of a small batch is one launch.
+// The pick table as dwords: block a's 20 row indices in 5 words (rows padded to 8 so that ONE s_load_dwordx8 fetches a row).  A FAM
+// launch is two-dimensional -- blockIdx.y = the block (depth * (A + 1) + child), blockIdx.x = the pass inside it, swept by 8 fronts like
+// the plain form -- so the block, and with it the table row, is known from the workgroup id alone: the row arrives by a scalar load
+// issued together with the kernel arguments, and a lane picks its slot's byte with two 64-bit selects and a shift.  Round 4 read the
+// table with a per-lane byte load, a second dependent memory round trip in front of every code gather, and a front workgroup LIVES
+// for its round trips: 0.52 of the HBM peak at 43008 walks against 0.95 for the plain code -> dense form (profiles/r05_family_front.json).
+struct FamilyRowWords {
+    uint32_t w[Cube3::A + 1][8];
+    constexpr FamilyRowWords() : w{} {
+        for (int a = 0; a <= Cube3::A; ++a)
+            for (int p = 0; p < Cube3::SLOTS; ++p) w[a][p >> 2] |= (uint32_t)kFamily<Cube3>.row[a][p] << (8 * (p & 3));
+    }
+};
+__constant__ FamilyRowWords c_family3_rows{};
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+struct FamilyBlocks { int64_t block_stride, src_depth_stride, dst_depth_stride; };
 template <class T, class E, int F, bool LDS, bool FAM = false>
 __global__ void __launch_bounds__(256) k_code_to_dense_front(const uint8_t *__restrict__ code, int64_t n, int64_t code_pitch, int shift, E *__restrict__ dense,
                                                              int64_t per_xcd, int64_t per_front, FamilyBlocks fam = {}) {
@@ -367,27 +381,32 @@ __global__ void __launch_bounds__(256) k_code_to_dense_front(const uint8_t *__re
     uint32_t ca[F], cb[F];
     bool live[F];
     // FAM: which block (child / parent) a global pass belongs to, its pass inside the block, and the input row of slot r there
-    int blk[F];                                                                  // child (A = the parent) inside its depth
-    int64_t lpass[F], src_off[F], dst_cube[F];                                   // pass inside the block; byte offset of the depth's record; first cube of the block
+    int64_t lpass[F];                                                            // pass (inside the block, FAM)
 #pragma unroll
-    for (int f = 0; f < F; ++f) {
-        const int64_t gp = pass0 + f * per_front;
-        int b = FAM ? (int)(gp / fam.ppb) : 0;
-        lpass[f] = FAM ? gp - (int64_t)b * fam.ppb : gp;
-        if (FAM && b >= fam.nblk) { b = fam.nblk - 1; lpass[f] = fam.ppb; }       // beyond the last block: lpass * CPP >= n, nothing live
-        const int g = FAM ? b / (T::A + 1) : 0;
-        blk[f] = b - g * (T::A + 1);
-        src_off[f] = FAM ? (int64_t)g * fam.src_depth_stride : 0;
-        dst_cube[f] = FAM ? (int64_t)g * fam.dst_depth_stride + (int64_t)blk[f] * fam.block_stride : 0;
+    for (int f = 0; f < F; ++f) lpass[f] = pass0 + f * per_front;
+    int64_t src_off = 0, dst_cube = 0;                                           // FAM: byte offset of the depth's record; first cube of the block
+    uint64_t rlo = 0, rmid = 0, rhi = 0;                                         // FAM: the block's 20 row indices (wave-uniform)
+    if constexpr (FAM) {
+        const uint32_t b = blockIdx.y, g = b / (uint32_t)(T::A + 1), a = b - g * (uint32_t)(T::A + 1);
+        src_off = (int64_t)g * fam.src_depth_stride;
+        dst_cube = (int64_t)g * fam.dst_depth_stride + (int64_t)a * fam.block_stride;
+        const u32x8 rw = *reinterpret_cast<const u32x8 *>(c_family3_rows.w[a]);
+        rlo = rw[0] | (uint64_t)rw[1] << 32;
+        rmid = rw[2] | (uint64_t)rw[3] << 32;
+        rhi = rw[4];
     }
-    auto in_row = [&](int f, int r) { return FAM ? (int)c_family3.row[blk[f]][r] : r; };
+    auto in_row = [&](int, int r) -> int {
+        if constexpr (!FAM) return r;
+        const uint64_t w = r < 8 ? rlo : r < 16 ? rmid : rhi;
+        return (int)((w >> (8 * (r & 7))) & 0xffu);
+    };
     if constexpr (LDS) {
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             const int64_t cube0 = lpass[f] * CPP, a0 = cube0 & ~(int64_t)3;
             if (tid < T::SLOTS * WORDS && cube0 < n && (f == 0 || per_front > 0)) {
                 const int r = tid / WORDS, w = tid - r * WORDS;
-                rows[f][tid] = *reinterpret_cast<const uint32_t *>(code + src_off[f] + tile_off(a0 + 4 * w, code_pitch, shift, ROWS) + (int64_t)in_row(f, r) * code_pitch);
+                rows[f][tid] = *reinterpret_cast<const uint32_t *>(code + src_off + tile_off(a0 + 4 * w, code_pitch, shift, ROWS) + (int64_t)in_row(f, r) * code_pitch);
             }
         }
         __syncthreads();
@@ -403,7 +422,7 @@ __global__ void __launch_bounds__(256) k_code_to_dense_front(const uint8_t *__re
                 ca[f] = (rows[f][ra * WORDS + (byte >> 2)] >> (8 * (byte & 3))) & 0xffu;
                 if constexpr (sizeof(E) == 1) cb[f] = (rows[f][rb * WORDS + (byte >> 2)] >> (8 * (byte & 3))) & 0xffu;
             } else {
-                const uint8_t *src = code + src_off[f] + tile_off(cube, code_pitch, shift, ROWS);   // row 0 of this cube's column
+                const uint8_t *src = code + src_off + tile_off(cube, code_pitch, shift, ROWS);   // row 0 of this cube's column
                 ca[f] = src[(int64_t)in_row(f, ra) * code_pitch];
                 if constexpr (sizeof(E) == 1) cb[f] = src[(int64_t)in_row(f, rb) * code_pitch];
             }
@@ -424,7 +443,7 @@ __global__ void __launch_bounds__(256) k_code_to_dense_front(const uint8_t *__re
             }
         }
         // the pass is 3840 contiguous bytes: thread t owns bytes 16 t ..
-        bst<4, RC_DENSE_AUX>(make_srd(dense + (dst_cube[f] + lpass[f] * CPP) * 480), (uint32_t)tid * 16u, 0, u);
+        bst<4, RC_DENSE_AUX>(make_srd(dense + (dst_cube + lpass[f] * CPP) * 480), (uint32_t)tid * 16u, 0, u);
     }
 }
 
@@ -702,6 +721,7 @@ __global__ void __launch_bounds__(kWave) k_adi(AdiArgs a) {
 
 // -------------------------------------------------------------------------- scramble
 struct ScrambleArgs {
+    const uint8_t *src;            // start states (== st: in place)
     uint8_t *st;
     int64_t n, pitch;
     int depth, shift;
@@ -724,8 +744,11 @@ __global__ void __launch_bounds__(kWave) k_scramble(ScrambleArgs a) {
     Pk<V> s[T::S];
     const __amdgpu_buffer_rsrc_t rows = make_srd(a.st + tile_off(g0, a.pitch, a.shift, T::S));
     const uint32_t rs = (uint32_t)a.pitch;
+    {
+        const __amdgpu_buffer_rsrc_t from = make_srd(a.src + tile_off(g0, a.pitch, a.shift, T::S));
 #pragma unroll
-    for (int i = 0; i < T::S; ++i) s[i] = bld<V, kAuxCached>(rows, lo, i * rs);
+        for (int i = 0; i < T::S; ++i) s[i] = bld<V, kAuxCached>(from, lo, i * rs);
+    }
     WalkRng rng[4 * V];
     if (a.actions_in == nullptr) {
 #pragma unroll
@@ -1079,6 +1102,25 @@ __global__ void __launch_bounds__(kWave) k_facade_expand(const uint8_t *st, uint
     if (lane == 0) __hip_atomic_store(reinterpret_cast<uint32_t *>(host_out + kFacadeSeq), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---------------------------------------------------- lockstep search: results per root (N2)
+// One expansion launch leaves leaf codes [tile][SLOTS][pitch], child codes [A][tile][SLOTS][pitch] and flags [A][tiles * pitch]; the
+// host trees (include/rubiktree.h: rc_tree_update) want one record per root.  One thread per (root, block) with block = child 0..A-1
+// or A = the leaf itself: SLOTS strided byte reads (coalesced across the roots of a wave), SLOTS contiguous bytes out.
+template <class T>
+__global__ void __launch_bounds__(256) k_search_pack(const uint8_t *__restrict__ leaf_code, const uint8_t *__restrict__ child_code,
+                                                     const uint8_t *__restrict__ child_solved, int64_t n, int64_t pitch, int shift, int64_t tiles,
+                                                     uint8_t *__restrict__ leaf_out, uint8_t *__restrict__ child_out, uint8_t *__restrict__ solved_out) {
+    const int64_t cube = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int blk = blockIdx.y;                                            // 0..A-1 children, A = the leaf
+    if (cube >= n) return;
+    const int64_t tile = shift >= 63 ? 0 : cube >> shift, col = cube - tile * pitch;
+    const uint8_t *src = (blk < T::A ? child_code + ((int64_t)blk * tiles + tile) * T::SLOTS * pitch : leaf_code + tile * T::SLOTS * pitch) + col;
+    uint8_t *dst = blk < T::A ? child_out + (cube * T::A + blk) * T::SLOTS : leaf_out + cube * T::SLOTS;
+#pragma unroll
+    for (int p = 0; p < T::SLOTS; ++p) dst[p] = src[(int64_t)p * pitch];
+    if (blk < T::A) solved_out[cube * T::A + blk] = child_solved[(int64_t)blk * tiles * pitch + cube];
+}
+
 // read-and-clear of the status word in one atomic, result into host-mapped memory
 __global__ void k_read_status(uint32_t *host_word) { *host_word = atomicExch(&g_status, 0u); }
 
@@ -1159,7 +1201,7 @@ int check_variant(int op, int A, int variant) {
         if (form == 3) ok = ok && units == 0;                                               // wide: tens = skew, field = groups / 16
         else if (form == 0 || form == 4) ok = ok && (units <= 2 || units == 4) && (tens == 0 || (tens >= 2 && tens <= 4)) && field == 0;   // front
         else ok = ok && units == 0 && tens == 0 && field == 0;
-    } else ok = false;
+    } else ok = false;                                                                       // RC_OP_FAMILY_TO_DENSE: no tuning fields
     return ok ? RC_OK : fail(RC_EINVAL, "variant: a field this entry point does not define is set (include/rubikhip.h RC_VARIANT_*)%s");
 }
 
@@ -1343,11 +1385,13 @@ struct FamilyDepths { int n_depths; int64_t src_depth_stride, dst_depth_stride; 
 template <class T, class E, int F, bool LDS>
 int launch_family_e(const uint8_t *fam, int64_t n, int64_t pitch, int sh, E *onehot, int64_t block_stride, FamilyDepths dp, hipStream_t st) {
     constexpr int cpp = 240 / (480 / (16 / (int)sizeof(E)));
-    const int64_t ppb = (n + cpp - 1) / cpp, passes = ppb * (T::A + 1) * dp.n_depths;
-    const int64_t per_front = (passes + 8 * F - 1) / (8 * F), per_xcd = per_front * F, blocks = per_front * 8;
+    const int64_t ppb = (n + cpp - 1) / cpp;                                      // passes per block
+    const int64_t per_front = (ppb + 8 * F - 1) / (8 * F), per_xcd = per_front * F, blocks = per_front * 8;   // gridDim.x % 8 == 0: x % 8 is the XCD in every row
     RC_GRID(blocks);
-    const FamilyBlocks fb{block_stride, ppb, dp.src_depth_stride, dp.dst_depth_stride, (T::A + 1) * dp.n_depths};
-    hipLaunchKernelGGL((k_code_to_dense_front<T, E, F, LDS, true>), dim3((unsigned)blocks), dim3(256), 0, st, fam, n, pitch, sh, onehot, per_xcd, per_front, fb);
+    const int64_t nblk = (int64_t)(T::A + 1) * dp.n_depths;
+    if (nblk > 65535) return fail(RC_EINVAL, "rc_onehot_from_family: at most 5041 depths per launch%s");
+    const FamilyBlocks fb{block_stride, dp.src_depth_stride, dp.dst_depth_stride};
+    hipLaunchKernelGGL((k_code_to_dense_front<T, E, F, LDS, true>), dim3((unsigned)blocks, (unsigned)nblk), dim3(256), 0, st, fam, n, pitch, sh, onehot, per_xcd, per_front, fb);
     RC_HIP(hipGetLastError());
     return RC_OK;
 }
@@ -1660,22 +1704,45 @@ int rc_apply_moves_ws(const uint8_t *in, uint8_t *out, const uint8_t *actions, i
                        workspace, workspace_bytes);
 }
 
-int rc_scramble(uint8_t *stp, int64_t n, int64_t pitch, int cube_size, int depth, uint64_t seed, uint64_t stream_id,
-                int64_t walk_offset, const uint8_t *actions_in, uint8_t *actions_out, int64_t act_pitch, uint8_t *done,
-                float *reward, void *stream) {
+int rc_scramble_from(const uint8_t *src, uint8_t *stp, int64_t n, int64_t pitch, int cube_size, int depth, uint64_t seed, uint64_t stream_id,
+                     int64_t walk_offset, const uint8_t *actions_in, uint8_t *actions_out, int64_t act_pitch, uint8_t *done,
+                     float *reward, void *stream) {
     RC_NEED_INIT();
     const int sh = tile_shift(pitch, n);
-    if (!stp || !aligned16(stp) || n < 0 || depth < 0 || sh < 0) return fail(RC_EINVAL, "rc_scramble: bad state buffer / pitch%s");
+    if (!stp || !aligned16(stp) || !src || !aligned16(src) || n < 0 || depth < 0 || sh < 0) return fail(RC_EINVAL, "rc_scramble: bad state buffer / pitch%s");
     if ((actions_in || actions_out) && bad_pitch(act_pitch, n)) return fail(RC_EINVAL, "rc_scramble: bad act_pitch%s");
     if ((actions_in && !aligned16(actions_in)) || (actions_out && !aligned16(actions_out))) return fail(RC_EINVAL, "rc_scramble: action buffers must be 16-byte aligned%s");
     if (reward && (reinterpret_cast<uintptr_t>(reward) & 15u)) return fail(RC_EINVAL, "reward must be 16-byte aligned%s");
     if (n == 0) return RC_OK;
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
-        ScrambleArgs a{stp, n, pitch, depth, sh, seed, stream_id, walk_offset, actions_in, actions_out, act_pitch, done, reward};
+        ScrambleArgs a{src, stp, n, pitch, depth, sh, seed, stream_id, walk_offset, actions_in, actions_out, act_pitch, done, reward};
         const int64_t blocks = (n + kWave * 4 - 1) / (kWave * 4);
         RC_GRID(blocks);
         hipLaunchKernelGGL((k_scramble<T>), dim3((unsigned)blocks), dim3(kWave), 0, S(stream), a);
+        RC_HIP(hipGetLastError());
+        return RC_OK;
+    });
+}
+
+int rc_scramble(uint8_t *stp, int64_t n, int64_t pitch, int cube_size, int depth, uint64_t seed, uint64_t stream_id,
+                int64_t walk_offset, const uint8_t *actions_in, uint8_t *actions_out, int64_t act_pitch, uint8_t *done,
+                float *reward, void *stream) {
+    return rc_scramble_from(stp, stp, n, pitch, cube_size, depth, seed, stream_id, walk_offset, actions_in, actions_out, act_pitch, done, reward, stream);
+}
+
+int rc_search_pack(const uint8_t *leaf_code, const uint8_t *child_code, const uint8_t *child_solved, int64_t n, int64_t pitch, int cube_size,
+                   uint8_t *leaf_out, uint8_t *child_out, uint8_t *solved_out, void *stream) {
+    RC_NEED_INIT();
+    const int sh = tile_shift(pitch, n, 20);
+    if (!leaf_code || !child_code || !child_solved || !leaf_out || !child_out || !solved_out || n < 0 || sh < 0) return fail(RC_EINVAL, "rc_search_pack: bad arguments%s");
+    if (n == 0) return RC_OK;
+    return by_size(cube_size, [&](auto t) {
+        using T = decltype(t);
+        const int64_t blocks = (n + 255) / 256, tiles = n <= pitch ? 1 : (n + pitch - 1) / pitch;
+        RC_GRID(blocks);
+        hipLaunchKernelGGL((k_search_pack<T>), dim3((unsigned)blocks, T::A + 1), dim3(256), 0, S(stream), leaf_code, child_code, child_solved, n, pitch, sh, tiles,
+                           leaf_out, child_out, solved_out);
         RC_HIP(hipGetLastError());
         return RC_OK;
     });
@@ -1854,7 +1921,7 @@ int rc_onehot_from_family_depths(const uint8_t *family, int64_t n, int64_t pitch
     if (!family || !aligned16(family) || n < 0 || sh < 0) return fail(RC_EINVAL, "bad family buffer / pitch%s");
     if (fmt < RC_FMT_U8 || fmt > RC_FMT_BF16 || !onehot || !aligned16(onehot)) return fail(RC_EINVAL, "rc_onehot_from_family: dense fmt and aligned buffer required%s");
     if (block_stride < n) return fail(RC_EINVAL, "rc_onehot_from_family: block_stride must be >= n_cubes%s");
-    if (n_depths < 0 || n_depths > 0xffff) return fail(RC_EINVAL, "rc_onehot_from_family: n_depths must be in 0..65535%s");
+    if (n_depths < 0 || n_depths > 5041) return fail(RC_EINVAL, "rc_onehot_from_family: n_depths must be in 0..5041%s");
     if (n == 0 || n_depths == 0) return RC_OK;
     const int64_t tiles = n <= pitch ? 1 : (n + pitch - 1) / pitch;
     const FamilyDepths dp{n_depths, tiles * kFamily<Cube3>.nf * pitch, (int64_t)(Cube3::A + 1) * block_stride};
@@ -1941,6 +2008,17 @@ static int facade_check_host(const uint8_t *host_out, uint32_t seq, const char *
     return RC_OK;
 }
 
+int rc_host_alias(const void *host, void **device_alias) {
+    if (!host || !device_alias) return fail(RC_EINVAL, "rc_host_alias: NULL argument%s");
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, host) != hipSuccess || attr.type != hipMemoryTypeHost || attr.devicePointer == nullptr) {
+        (void)hipGetLastError();
+        return fail(RC_EINVAL, "rc_host_alias: not host-mapped pinned memory (hipHostMalloc / hipHostRegister / torch pin_memory)%s");
+    }
+    *device_alias = attr.devicePointer;
+    return RC_OK;
+}
+
 int rc_facade_steps(uint8_t *stp, int64_t pitch, int cube_size, const uint8_t *actions, int n_actions, uint8_t *host_out, uint32_t seq,
                     int wait, void *stream) {
     RC_NEED_INIT();
@@ -2013,7 +2091,8 @@ int rc_facade_expand(const uint8_t *stp, int64_t pitch, int cube_size, uint8_t *
 int rc_describe_dispatch(int op, int cube_size, int64_t n, int depth, unsigned outputs, int fmt, int variant, char *buf, int buflen) {
     if (!buf || buflen < 16) return fail(RC_EINVAL, "rc_describe_dispatch: buffer too small%s");
     if (n <= 0) return fail(RC_EINVAL, "rc_describe_dispatch: n must be positive%s");
-    if (op != RC_OP_STEP && op != RC_OP_EXPAND && op != RC_OP_ADI && op != RC_OP_CODE_TO_DENSE) return fail(RC_EINVAL, "rc_describe_dispatch: unknown op%s");
+    if (op != RC_OP_STEP && op != RC_OP_EXPAND && op != RC_OP_ADI && op != RC_OP_CODE_TO_DENSE && op != RC_OP_FAMILY_TO_DENSE)
+        return fail(RC_EINVAL, "rc_describe_dispatch: unknown op%s");
     if (int rc = check_variant(op, cube_size == 2 ? 6 : 12, variant)) return rc;
     return by_size(cube_size, [&](auto t) {
         using T = decltype(t);
@@ -2058,6 +2137,16 @@ int rc_describe_dispatch(int op, int cube_size, int64_t n, int depth, unsigned o
             } else {
                 snprintf(buf, buflen, "k_code_to_dense<%s,%s,TILE=%d> grid=%lld block=%d", cube, names[fmt], (int)form, (long long)dense_grid((n + (int)form - 1) / (int)form, fmt), kDenseBlock);
             }
+            return RC_OK;
+        }
+        if (op == RC_OP_FAMILY_TO_DENSE) {
+            static const char *const names[] = {"", "", "u8", "f16", "f32", "bf16"};
+            if (T::SIZE != 3 || fmt < RC_FMT_U8 || fmt > RC_FMT_BF16) return fail(RC_EINVAL, "rc_describe_dispatch: 3x3x3 and a dense fmt required%s");
+            if (depth <= 0) return fail(RC_EINVAL, "rc_describe_dispatch: depth (the number of depths per launch) must be positive%s");
+            const int cpp = fmt == RC_FMT_F32 ? 2 : fmt == RC_FMT_U8 ? 8 : 4, f = fmt == RC_FMT_U8 ? 2 : 1;   // launch_family_to_dense's shapes
+            const int64_t ppb = (n + cpp - 1) / cpp;
+            snprintf(buf, buflen, "k_code_to_dense_front<%s,%s,F=%d,%s,family> depths=%d cubes_per_pass=%d xcd grid=%lldx%d block=256", cube, names[fmt], f,
+                     fmt == RC_FMT_F32 ? "gather" : "lds", depth, cpp, (long long)((ppb + 8 * f - 1) / (8 * f) * 8), (T::A + 1) * depth);
             return RC_OK;
         }
         if (op == RC_OP_EXPAND) {

@@ -212,7 +212,7 @@ class BatchedMCTS:
         hv = lambda name: hp[off[name][0]:off[name][0] + off[name][1]]
         self._host = (hv("leaf").reshape(n, SL), hv("child").reshape(n, A, SL), hv("solved").reshape(n, A),
                       hv("value").view(np.float32), hv("policy").view(np.float32).reshape(n, A))
-        self.graph, self._graphs, self._paths, self._paths_host = bool(graph), {}, None, None
+        self.graph, self._graphs, self._paths = bool(graph), {}, None
 
     def __getattr__(self, name):
         # result views of the native trees under the names the Python tree uses (solution, sims_used, trees[r][b"root"]);
@@ -235,15 +235,17 @@ class BatchedMCTS:
         raise AttributeError(name)
 
     def _device_step(self, depth):
-        """Kernels of one simulation, all on the current stream (capturable): roots -> work, replay `depth`
-        moves from self._paths, expansion, leaf code + one-hot, net forward."""
+        """Kernels and the download of one simulation, all on the current stream (capturable): roots replayed `depth` moves into work
+        (rc_scramble_from reads self._paths from pinned host memory), expansion, leaf code, ONE launch that lays codes and flags out
+        per root (rc_search_pack), one-hot, net forward, value + policy into the same block, one D2H copy of the block.
+        (Sending codes + flags on a side stream while the net runs was measured and loses: 246 us against 211 us per call under
+        hipGraph -- as every two-branch graph on this stack; profiles/r05_mcts.json.)"""
         n, cs = self.n, self.cube_size
-        self.work.copy_(self.roots)
-        if depth:
-            ops.scramble(self.work, n, cs, depth, actions_in=self._paths[:depth])
+        ops.scramble(self.work, n, cs, depth, actions_in=self._paths[:depth] if depth else None, src=self.roots)
         pitch = self.work.shape[-1]
         ops.expand_children(self.work, n, cs, None, self.ex["child_solved"], self.ex["child_code"], pitch=pitch)
         ops.encode(self.work, n, cs, self.code, _lib.FMT_CODE)
+        ops.search_pack(self.code, self.ex["child_code"], self.ex["child_solved"], n, cs, self._leaf_aos, self._child_aos, self._solved_aos)
         ops.onehot_from_code(self.code, n, cs, self.onehot)
         value, logits = self.model(self.onehot)
         if logits.dtype == torch.float32:
@@ -251,31 +253,30 @@ class BatchedMCTS:
         else:
             self._policy_dev.copy_(torch.softmax(logits, dim=-1))
         self._value_dev.copy_(value.reshape(-1))
-        self._leaf_aos.copy_(ops.to_aos(self.code, n))
-        cc = self.ex["child_code"]                                              # [A, tiles, SLOTS, pitch]
-        self._child_aos.copy_(cc.permute(1, 3, 0, 2).reshape(-1, self.A, cc.shape[2])[:n])
-        self._solved_aos.copy_(self.ex["child_solved"][:, :n].t())
+        self._pack_host.copy_(self._pack_dev, non_blocking=True)
 
     @torch.no_grad()
     def leaves_step(self, paths, copy=True):
         """Device part of one simulation for `paths` (uint8 [R, depth], no-op padded).  With graph=True the
         kernel sequence is captured once per depth bucket as a hipGraph (paths padded with the no-op up to the
-        bucket) and replayed: one launch instead of ~15 (DESIGN.md "Config 5").  One upload (the paths, from a pinned staging
-        buffer), one download (the packed result block), one synchronisation.  Returns host arrays (leaf code [R, SLOTS], child code
+        bucket) and replayed: one launch instead of ~15 (DESIGN.md "Config 5").  No upload (the replay kernel reads the paths from
+        pinned host memory), one download (the packed result block), one synchronisation.  Returns host arrays (leaf code [R, SLOTS], child code
         [R, A, SLOTS], solved [R, A], value [R], policy [R, A]); copy=False hands out views of the pinned block, valid until
         the next call."""
         n = self.n
         depth = paths.shape[1]
         if self._paths is None or self._paths.shape[0] < depth:
+            # the descents live in PINNED host memory that the replay kernel reads in place (rc_host_alias): no upload
             cap = max(16, 1 << max(depth - 1, 0).bit_length())
-            self._paths = torch.full((cap, _lib.pitch_for(n)), self.A, dtype=torch.uint8, device=self.dev)
-            self._paths_host = torch.full((cap, _lib.pitch_for(n)), self.A, dtype=torch.uint8).pin_memory()
+            self._paths = torch.full((cap, _lib.pitch_for(n)), self.A, dtype=torch.uint8).pin_memory()
+            self._paths_np = self._paths.numpy()
+            self._path_rows = cap                                                          # rows that may hold moves (the rest is the no-op already)
             self._graphs = {}
-        ph = self._paths_host.numpy()
-        ph.fill(self.A)
+        rows = min(self._paths.shape[0], max(4, 1 << max(depth - 1, 0).bit_length())) if depth else 0   # what a replay of this depth reads
+        self._paths_np[depth:max(rows, self._path_rows)].fill(self.A)                     # rows behind the descents: back to the no-op
+        self._path_rows = rows
         if depth:
-            ph[:depth, :n] = paths.T
-        self._paths.copy_(self._paths_host, non_blocking=True)
+            self._paths_np[:depth, :n] = paths.T
         if self.graph:
             bucket = 0 if depth == 0 else max(4, 1 << (depth - 1).bit_length())      # replay length: no-op padded
             bucket = min(bucket, self._paths.shape[0])
@@ -292,8 +293,7 @@ class BatchedMCTS:
             self._graphs[bucket].replay()
         else:
             self._device_step(depth)
-        self._pack_host.copy_(self._pack_dev, non_blocking=True)
-        torch.cuda.current_stream(self.dev).synchronize()
+        torch.cuda.current_stream(self.dev).synchronize()                          # the downloads are part of the device step
         code_h, cc_h, cs_h, v_h, p_h = self._host
         if not copy:
             return code_h, cc_h, cs_h, v_h, p_h

@@ -12,6 +12,8 @@ one-tile ("plain") buffers.
 """
 from __future__ import annotations
 
+import threading
+
 import torch
 
 from . import _lib
@@ -124,21 +126,34 @@ def _onehot_args(onehot, fmt, n, cube_size, what):
 
 
 _workspaces = {}     # (device index, stream handle) -> uint8 tensor; grown on demand, never shared between streams
+_ws_lock = threading.Lock()
+_WS_MAX = 8          # cached workspaces (streams come and go: the oldest entry is dropped beyond this)
 
 
 def workspace(device, nbytes):
     """Scratch tensor for rc_apply_moves_ws on `device`'s CURRENT stream (the library allocates nothing: the caller owns it).
-    One per (device, stream): launches of one stream are ordered, so reusing it between calls is safe."""
+    One per (device, stream): launches of one stream are ordered, so reusing it between calls is safe -- provided the two launches of
+    one call are queued back to back, which is why apply_moves / encode hold `_ws_lock` from this look-up until the C call has
+    returned (two host threads driving ONE stream would otherwise interleave step(T1), step(T2), front(T1)).  At most _WS_MAX
+    workspaces are kept (20 bytes per cube each); release_workspaces() drops them all."""
     device = torch.device(device)
     if torch.cuda.is_current_stream_capturing():
         # under hipGraph capture the allocation belongs to the graph's private pool and lives exactly as long as the graph: never cached
         return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
     key = (device.index if device.index is not None else torch.cuda.current_device(), stream_ptr(device).value)
-    ws = _workspaces.get(key)
+    ws = _workspaces.pop(key, None)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
+    _workspaces[key] = ws                                         # most recently used last
+    while len(_workspaces) > _WS_MAX:
+        _workspaces.pop(next(iter(_workspaces)))                   # the caching allocator keeps the block alive for launches still queued
     return ws
+
+
+def release_workspaces():
+    """Drop every cached rc_apply_moves_ws workspace (they are re-created on demand)."""
+    with _ws_lock:
+        _workspaces.clear()
 
 
 def apply_moves(src, dst, actions, n, cube_size, reward=None, done=None, onehot=None, fmt=FMT_NONE, variant=0):
@@ -159,28 +174,66 @@ def apply_moves(src, dst, actions, n, cube_size, reward=None, done=None, onehot=
         return
     need = lib().rc_workspace_bytes(_lib.OP_STEP, cube_size, n, fmt) if fmt >= _lib.FMT_U8 else 0
     if need > 0:
-        ws = workspace(src.device, need)
-        check(lib().rc_apply_moves_ws(ptr(src), ptr(dst), ptr(actions), n, p_in, p_out, cube_size, ptr(reward), ptr(done),
-                                      ptr(oh), fmt, cp, ptr(ws), ws.numel(), stream_ptr(src.device)))
+        with _ws_lock:
+            ws = workspace(src.device, need)
+            check(lib().rc_apply_moves_ws(ptr(src), ptr(dst), ptr(actions), n, p_in, p_out, cube_size, ptr(reward), ptr(done),
+                                          ptr(oh), fmt, cp, ptr(ws), ws.numel(), stream_ptr(src.device)))
         return
     check(lib().rc_apply_moves(ptr(src), ptr(dst), ptr(actions), n, p_in, p_out, cube_size, ptr(reward), ptr(done),
                                ptr(oh), fmt, cp, stream_ptr(src.device)))
 
 
 def scramble(st, n, cube_size, depth, seed=0, stream_id=0, walk_offset=0, actions_in=None, actions_out=None,
-             done=None, reward=None):
-    """reset()'s scramble loop in place (cube_env.py:65-67); actions_* are [depth, pitch] uint8."""
+             done=None, reward=None, src=None):
+    """reset()'s scramble loop in place (cube_env.py:65-67); actions_* are [depth, pitch] uint8.
+    actions_in may also be a PINNED host tensor: the kernel then reads the moves straight from host memory (no upload; the lockstep
+    search hands its tree descents over this way).
+    src: read the start states from this buffer (same shape as st) instead of st: st = src moved, src untouched (rc_scramble_from;
+    with depth 0 a plain copy)."""
     S, _, _ = _size(cube_size)
     pitch = _tiled(st, S, n, "scramble")
+    if src is not None and (_tiled(src, S, n, "scramble src") != pitch or src.shape != st.shape):
+        raise RubikHipError("scramble: src and st must share one shape")
     ap = 0
-    for a in (actions_in, actions_out):
-        if a is not None:
-            ap = _rows(a, depth, n, "scramble actions")
+    a_in = ptr(actions_in)
+    if actions_in is not None and not actions_in.is_cuda:
+        if actions_in.dtype != torch.uint8 or actions_in.dim() != 2 or actions_in.shape[0] != depth or not actions_in.is_contiguous() or \
+                actions_in.shape[1] < n or actions_in.shape[1] % 16:
+            raise RubikHipError(f"scramble actions (host): need a contiguous pinned uint8 tensor [{depth}, pitch >= n, pitch % 16 == 0]")
+        a_in, ap = _lib.host_alias(actions_in), actions_in.shape[1]
+    elif actions_in is not None:
+        ap = _rows(actions_in, depth, n, "scramble actions")
+    if actions_out is not None:
+        ap2 = _rows(actions_out, depth, n, "scramble actions")
+        if actions_in is not None and ap2 != ap:
+            raise RubikHipError("scramble: actions_in and actions_out must share one pitch")
+        ap = ap2
     _vec(reward, n, torch.float32, "reward")
     _vec(done, n, torch.uint8, "done")
     _lib.init(st.device)
-    check(lib().rc_scramble(ptr(st), n, pitch, cube_size, depth, seed, stream_id, walk_offset, ptr(actions_in),
+    if src is not None:
+        check(lib().rc_scramble_from(ptr(src), ptr(st), n, pitch, cube_size, depth, seed, stream_id, walk_offset, a_in,
+                                     ptr(actions_out), ap, ptr(done), ptr(reward), stream_ptr(st.device)))
+        return
+    check(lib().rc_scramble(ptr(st), n, pitch, cube_size, depth, seed, stream_id, walk_offset, a_in,
                             ptr(actions_out), ap, ptr(done), ptr(reward), stream_ptr(st.device)))
+
+
+def search_pack(leaf_code, child_code, child_solved, n, cube_size, leaf_out, child_out, solved_out):
+    """The results of one expansion launch, laid out per root for the host trees of a lockstep search (rc_search_pack):
+    leaf_code [tiles, SLOTS, pitch], child_code [A, tiles, SLOTS, pitch], child_solved [A, tiles * pitch]  ->
+    leaf_out [n, SLOTS], child_out [n, A, SLOTS], solved_out [n, A] (uint8, contiguous)."""
+    _, A, SL = _size(cube_size)
+    pitch = _tiled(leaf_code, SL, n, "search_pack leaf_code")
+    tiles = _tiles_of(n, pitch)
+    _out(child_code, (A,), tiles, SL, pitch, "search_pack child_code")
+    _out(child_solved, (A,), tiles, 0, pitch, "search_pack child_solved")
+    for t, shape, what in ((leaf_out, (n, SL), "leaf_out"), (child_out, (n, A, SL), "child_out"), (solved_out, (n, A), "solved_out")):
+        if t.dtype != torch.uint8 or not t.is_cuda or not t.is_contiguous() or tuple(t.shape) != shape:
+            raise RubikHipError(f"search_pack: {what} must be a contiguous uint8 HIP tensor {shape}")
+    _lib.init(leaf_code.device)
+    check(lib().rc_search_pack(ptr(leaf_code), ptr(child_code), ptr(child_solved), n, pitch, cube_size, ptr(leaf_out), ptr(child_out), ptr(solved_out),
+                               stream_ptr(leaf_code.device)))
 
 
 def legacy_scramble_actions(seeds, cube_size, scramble_count, device=None, variant=0):
@@ -227,8 +280,9 @@ def encode(st, n, cube_size, onehot, fmt):
     _lib.init(st.device)
     need = lib().rc_workspace_bytes(_lib.OP_STEP, cube_size, n, fmt) if fmt >= _lib.FMT_U8 else 0
     if need > 0:                                                 # large dense batches: codes into the workspace, then the front writer
-        ws = workspace(st.device, need)
-        check(lib().rc_encode_ws(ptr(st), n, pitch, cube_size, ptr(oh), fmt, cp, ptr(ws), ws.numel(), stream_ptr(st.device)))
+        with _ws_lock:
+            ws = workspace(st.device, need)
+            check(lib().rc_encode_ws(ptr(st), n, pitch, cube_size, ptr(oh), fmt, cp, ptr(ws), ws.numel(), stream_ptr(st.device)))
         return
     check(lib().rc_encode(ptr(st), n, pitch, cube_size, ptr(oh), fmt, cp, stream_ptr(st.device)))
 

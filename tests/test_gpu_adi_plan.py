@@ -278,3 +278,61 @@ def test_facade_release_from_another_thread(L):
     assert (results[0] == s2).all()
     env.close()
     ref.close()
+
+
+@pytest.mark.parametrize("cs", [3, 2])
+def test_scramble_from_pinned_paths_and_search_pack(ops, L, oracle, cs):
+    """The lockstep search's device step in pieces: rc_scramble_from replays no-op padded descents that it reads from PINNED HOST memory
+    (rc_host_alias) out of untouched root states, and rc_search_pack lays the expansion's codes and flags out per root -- against the
+    oracle and against the plain torch transposes round 4 used."""
+    A, SL = (12, 20) if cs == 3 else (6, 7)
+    for n, pitch in ((4096, None), (5000, 1024), (70000, None)):
+        roots = ops.alloc_states(n, cs, "cuda", pitch)
+        ops.fill_solved(roots, n, cs)
+        ops.scramble(roots, n, cs, 9, seed=4, stream_id=2)
+        snap = roots.clone()
+        rng = np.random.default_rng(n)
+        depth = 6
+        lens = rng.integers(0, depth + 1, n)
+        paths = rng.integers(0, A, (n, depth), dtype=np.uint8)
+        paths[np.arange(depth)[None, :] >= lens[:, None]] = A                      # ragged descents, padded with the no-op
+        host = torch.full((8, L.pitch_for(n)), A, dtype=torch.uint8).pin_memory()
+        host.numpy()[:depth, :n] = paths.T
+        work = torch.full_like(roots, 9)
+        done = torch.empty(n, dtype=torch.uint8, device="cuda")
+        ops.scramble(work, n, cs, depth, actions_in=host[:depth], src=roots, done=done)
+        assert torch.equal(roots, snap)                                            # the roots are read only
+        st = ops.to_aos(snap, n).cpu().numpy()
+        for d in range(depth):
+            live = paths[:, d] < A
+            if live.any():
+                st[live] = oracle.step(cs, st[live], paths[live, d], threads=4)[0]
+        assert (ops.to_aos(work, n).cpu().numpy() == st).all()
+        assert (done.cpu().numpy() == oracle.is_solved(cs, st)).all() if n <= 5000 else True
+        dev_paths = host.cuda()
+        work2 = torch.empty_like(roots)
+        ops.scramble(work2, n, cs, depth, actions_in=dev_paths[:depth], src=roots)  # the same from device memory
+        assert torch.equal(ops.to_aos(work2, n), ops.to_aos(work, n))               # (columns past n are never written)
+        ops.scramble(work2, n, cs, 0, src=roots)                                    # depth 0: a copy
+        assert torch.equal(ops.to_aos(work2, n), ops.to_aos(roots, n))
+        # expansion of the leaves -> one record per root
+        p = work.shape[-1]
+        ex = ops.expand_buffers(n, cs, "cuda", p, children=False, codes=True)
+        ops.expand_children(work, n, cs, None, ex["child_solved"], ex["child_code"], pitch=p)
+        code = ops.alloc_code(n, cs, "cuda", p)
+        ops.encode(work, n, cs, code, L.FMT_CODE)
+        leaf = torch.zeros((n, SL), dtype=torch.uint8, device="cuda")
+        child = torch.zeros((n, A, SL), dtype=torch.uint8, device="cuda")
+        solved = torch.zeros((n, A), dtype=torch.uint8, device="cuda")
+        ops.search_pack(code, ex["child_code"], ex["child_solved"], n, cs, leaf, child, solved)
+        cc = ex["child_code"]
+        assert torch.equal(leaf, ops.to_aos(code, n)) and torch.equal(solved, ex["child_solved"][:, :n].t().contiguous())
+        assert torch.equal(child, cc.permute(1, 3, 0, 2).reshape(-1, A, SL)[:n].contiguous())
+        _, e_cc, e_cs = oracle.expand(cs, st[:3000], threads=4)
+        assert (child[:3000].cpu().numpy() == e_cc).all() and (solved[:3000].cpu().numpy() == e_cs).all()
+    with pytest.raises(L.RubikHipError):
+        ops.scramble(work, n, cs, depth, actions_in=torch.zeros((depth, L.pitch_for(n)), dtype=torch.uint8), src=roots)   # pageable host memory
+    with pytest.raises(L.RubikHipError):
+        ops.scramble(work, n, cs, depth, actions_in=host[:depth], src=roots[:1])
+    with pytest.raises(L.RubikHipError):
+        ops.search_pack(code, ex["child_code"], ex["child_solved"], n, cs, leaf, child[:, :3], solved)

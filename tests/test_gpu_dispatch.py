@@ -119,12 +119,15 @@ def test_adi_every_parts_value(ops, L, oracle, cs, v, n_walks, depth, pitch):
 @pytest.mark.parametrize("v", [1, 2])
 def test_adi_depth_segments(ops, L, oracle, cs, v):
     """Depth segments of the ADI kernel (a wave replays the moves of the earlier depths and emits only its own range): every
-    segment count 1..depth and beyond (clamped), alone and combined with parts, drawn and replayed moves -- all outputs
+    segment count 1..depth and beyond (clamped to the depth), alone and combined with parts, drawn and replayed moves -- all outputs
     against the oracle (cube_env.py:177-194,212-236)."""
     n_walks, depth = 3000, 7
     exp = oracle.adi(cs, n_walks, depth, seed=91, stream=4, walk0=11, threads=8)
     wp = None
-    for segs, parts in ((1, 1), (2, 1), (3, 2), (4, 1), (5, 3), (7, 1), (7, 6), (12, 1), (16, 2), (40, 1)):
+    with pytest.raises(L.RubikHipError, match="variant"):           # the segment field is 1..16 (RC_VARIANT_ADI_SEGS): the launcher rejects the rest
+        pt, bufs = ops.adi_buffers(n_walks, depth, cs, "cuda", 1024, parents=True)
+        ops.adi_generate(n_walks, depth, cs, pt, "cuda", seed=91, variant=40 * 1000000 + v, **bufs)
+    for segs, parts in ((1, 1), (2, 1), (3, 2), (4, 1), (5, 3), (7, 1), (7, 6), (12, 1), (16, 2), (16, 1)):
         pt, bufs = ops.adi_buffers(n_walks, depth, cs, "cuda", 1024, parents=True, parent_code=True, children=True, child_code=True)
         for t in bufs.values():
             t.fill_(7)

@@ -110,9 +110,9 @@ def test_abi_exports_every_declared_symbol():
     assert len(declared) >= 15
     for name in declared:
         assert hasattr(L, name), name
-    assert L.rc_version() >= 500 and len(declared) == 33 and {"rc_describe_dispatch", "rc_facade_release", "rc_apply_moves_ws", "rc_encode_ws", "rc_workspace_bytes",
+    assert L.rc_version() >= 500 and len(declared) == 36 and {"rc_describe_dispatch", "rc_facade_release", "rc_apply_moves_ws", "rc_encode_ws", "rc_workspace_bytes",
                                                               "rc_adi_generate_family", "rc_family_layout", "rc_onehot_from_family", "rc_onehot_from_family_depths",
-                                                              "rc_adi_targets_depths", "rc_legacy_scramble_actions_ex"} <= declared
+                                                              "rc_adi_targets_depths", "rc_legacy_scramble_actions_ex", "rc_host_alias", "rc_scramble_from", "rc_search_pack"} <= declared
     # every rc_* the library exports is declared in the header, and nothing else leaves it
     import subprocess
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
@@ -199,6 +199,13 @@ def test_dispatch_description_and_enodev_without_gpu():
     assert L.describe(L.OP_ADI, 3, 100000, 30, outputs=L.OUT_CODE | L.OUT_FLAGS).startswith("k_adi<Cube3,V=2,code> parts=1 segs=3 grid=588")
     assert "segs=5 " in L.describe(L.OP_ADI, 3, 100000, 5, outputs=L.OUT_CODE, variant=9001001)       # clamped to the depth
     assert "V=1," in L.describe(L.OP_STEP, 3, 1 << 22, outputs=st, variant=1) and "POL=0" in L.describe(L.OP_STEP, 3, 1 << 22, outputs=st, variant=20)
+    # the ADI pipeline's block writer: 13 blocks per depth, several depths per launch, the front writer's shapes per format
+    assert L.describe(L.OP_FAMILY_TO_DENSE, 3, 43008, 1, fmt=L.FMT_F32) == "k_code_to_dense_front<Cube3,f32,F=1,gather,family> depths=1 cubes_per_pass=2 xcd grid=21504x13 block=256"
+    assert L.describe(L.OP_FAMILY_TO_DENSE, 3, 200, 30, fmt=L.FMT_BF16).startswith("k_code_to_dense_front<Cube3,bf16,F=1,lds,family> depths=30 cubes_per_pass=4 xcd grid=56x390 ")
+    assert L.describe(L.OP_FAMILY_TO_DENSE, 3, 200, 30, fmt=L.FMT_U8).startswith("k_code_to_dense_front<Cube3,u8,F=2,lds,family> depths=30 cubes_per_pass=8 xcd grid=16x390 ")
+    for bad in (dict(cube_size=2, fmt=L.FMT_F32), dict(cube_size=3, fmt=L.FMT_CODE), dict(cube_size=3, fmt=L.FMT_F32, variant=1), dict(cube_size=3, fmt=L.FMT_F32, depth=0)):
+        with pytest.raises(L.RubikHipError):
+            L.describe(L.OP_FAMILY_TO_DENSE, bad["cube_size"], 100, bad.get("depth", 2), fmt=bad["fmt"], variant=bad.get("variant", 0))
     with pytest.raises(L.RubikHipError):
         L.describe(99, 3, 10)
     with pytest.raises(L.RubikHipError):

@@ -53,11 +53,15 @@ def main():
         lo, hi = groups[k][-1], groups[k + 1][0]
         t0, t1 = rows[lo][1], rows[hi][0]
         cls = {"env": 0, "gemm": 0, "net_elementwise": 0, "glue": 0}
+        env_detail = {"k_adi": 0, "k_code_to_dense_front": 0, "k_adi_targets": 0, "other": 0}
         per_kernel = {}
         busy, cur_end, launches = 0, t0, 0
         for s, e, name in rows[lo + 1:hi]:
             c = classify(name)
             cls[c] += e - s
+            if c == "env":
+                key = "k_adi_targets" if "k_adi_targets" in name else "k_adi" if "k_adi<" in name else "k_code_to_dense_front" if "k_code_to_dense_front" in name else "other"
+                env_detail[key] += e - s
             launches += 1
             short = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:70]
             pk = per_kernel.setdefault(short, [0, 0])
@@ -69,6 +73,7 @@ def main():
                 cur_end = e
         window = t1 - t0
         calls.append({"window_us": window / 1e3, "launches": launches, **{k_ + "_us": v / 1e3 for k_, v in cls.items()},
+                      "env_detail_us": {k_: round(v / 1e3, 1) for k_, v in env_detail.items()},
                       "idle_us": (window - busy) / 1e3,
                       "top_kernels": {k_: {"calls": v[0], "us": round(v[1] / 1e3, 1)} for k_, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])[:8]}})
     calls.sort(key=lambda c: c["window_us"])

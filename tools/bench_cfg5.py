@@ -131,26 +131,30 @@ def run(short=False, iters=None, sims=20):
     # whole simulations of the lockstep search (host trees in librubiktree.so + the device step + transfers), split per phase
     import random
     bm = BatchedMCTS(model, leaves, n, cs, graph=True, rngs=[random.Random(r) for r in range(n)])
-    for _ in range(10):
+    for _ in range(30):                                              # past the first graph captures (depth buckets 4, 8, 16)
         bm.simulate()
     torch.cuda.synchronize()
-    split = {"select": 0.0, "device_and_transfers": 0.0, "update": 0.0}
-    t_all = time.perf_counter()
-    for _ in range(sims):
-        t0 = time.perf_counter()
-        p = bm.native.select()
-        t1 = time.perf_counter()
-        out = bm.leaves_step(p, copy=False)
-        t2 = time.perf_counter()
-        bm.native.update(*out)
-        t3 = time.perf_counter()
-        split["select"] += t1 - t0
-        split["device_and_transfers"] += t2 - t1
-        split["update"] += t3 - t2
-    total = time.perf_counter() - t_all
-    res["batched_mcts_simulate_native_tree_ms"] = total / sims * 1e3
-    res["batched_mcts_simulate_split_us"] = {k: v / sims * 1e6 for k, v in split.items()}
-    res["batched_mcts_note"] = (f"simulations 11-{10 + sims} of 4096 roots, per-root generators, hipGraph device step, one packed download; select / update = "
+    buckets = sorted(bm._graphs)
+    for copy in (False, True):                                       # the trees read the pinned download block in place / private copies of it
+        split = {"select": [], "device_and_transfers": [], "update": []}
+        t_all = time.perf_counter()
+        for _ in range(sims):
+            t0 = time.perf_counter()
+            p = bm.native.select()
+            t1 = time.perf_counter()
+            out = bm.leaves_step(p, copy=copy)
+            t2 = time.perf_counter()
+            bm.native.update(*out)
+            t3 = time.perf_counter()
+            split["select"].append(t1 - t0)
+            split["device_and_transfers"].append(t2 - t1)
+            split["update"].append(t3 - t2)
+        total = time.perf_counter() - t_all
+        tag = "_copied_results" if copy else ""
+        res[f"batched_mcts_simulate_native_tree{tag}_ms"] = total / sims * 1e3
+        res[f"batched_mcts_simulate_split{tag}_us"] = {k: sorted(v)[len(v) // 2] * 1e6 for k, v in split.items()}      # medians
+    res["batched_mcts_graph_buckets"] = {"before": buckets, "after": sorted(bm._graphs)}
+    res["batched_mcts_note"] = (f"simulations 31-{30 + 2 * sims} of 4096 roots, per-root generators, hipGraph device step, one packed download; select / update = "
                                 "librubiktree.so (C++ / OpenMP on this job's CPU share); the pure-Python tree needs 100-500 ms per simulation")
     return res
 

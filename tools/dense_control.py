@@ -38,7 +38,6 @@ BUILDS = {                      # name -> -D switches
     "aux0_pipe4": ["-DRC_DENSE_PIPE=4", "-DRC_DENSE_AUX=0"],
     "aux2_pipe4": ["-DRC_DENSE_PIPE=4", "-DRC_DENSE_AUX=2"],
     "aux17_pipe4": ["-DRC_DENSE_PIPE=4", "-DRC_DENSE_AUX=17"],
-    "gather": ["-DRC_FRONT_LDS=0"],          # front writer: one byte gather per lane instead of wave 0's load + LDS
 }
 
 
@@ -136,7 +135,7 @@ def main():
     _lib.init(dev)
     for name in BUILDS:
         path = os.path.join(CTL, f"librubikhip_{name}.so")
-        if os.path.exists(path) and (not args.quick or name == "gather"):
+        if os.path.exists(path) and not args.quick:
             L = ctypes.CDLL(path)
             if not hasattr(L, "rc_onehot_from_family"):
                 print(f"# {path} is a build of older sources: rebuild with --build", file=sys.stderr)
@@ -221,12 +220,11 @@ def main():
                                     ("fused_ws: step+code, front (rc_apply_moves_ws)", lambda: fused_ws(oh), 114)):
                 t = timeit(fn)
                 emit(what=what, lib="shipped", us=t, frac=frac(t, extra), **common)
-            if "gather" in libs:
-                for what, v in (("c2d_front_xcd", 0 if fmt != _lib.FMT_U8 else 400000), ("c2d_front_linear", 400020)):
-                    t = timeit(lambda: c2d(libs["gather"], oh, fmt, v))
-                    emit(what=what, lib="gather", us=t, frac=frac(t, 20), **common)
-                t = timeit(lambda: c2d(libs["shipped"], oh, fmt, 400000))
-                emit(what="c2d_front_xcd", lib="shipped(lds)", us=t, frac=frac(t, 20), **common)
+            # how the front writer fetches its code bytes, on the SHIPPED library: RC_VARIANT_DENSE_FRONT_FETCH 3 = a byte gather per
+            # lane, 4 = one load of wave 0 + LDS (round 4 compared a -DRC_FRONT_LDS=0 build; that macro is gone, the variant replaced it)
+            for what, v in (("c2d_front_xcd fetch=gather", 400030), ("c2d_front_xcd fetch=lds", 400040)):
+                t = timeit(lambda: c2d(libs["shipped"], oh, fmt, v))
+                emit(what=what, lib="shipped", us=t, frac=frac(t, 20), **common)
             for lname, L in libs.items():
                 if args.pmc and lname not in ("shipped", "pipe1", "ctrl1_pipe1", "ctrl2_pipe1", "ctrl2_pipe4"):
                     continue

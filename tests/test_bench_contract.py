@@ -55,7 +55,25 @@ def test_bench_json_line():
         assert rr["algorithmic_bytes_per_launch"] > 0
     adi = [x for x in recs if x["config"].startswith("config 3")][0]
     assert adi["roofline"]["bytes_per_unit"] == 715 and adi["roofline"]["frac"] > 0.6
-    assert "hipgraph_serial_step_us" in d["configs"]["config5_mcts_4096_leaves"]
+    c5 = d["configs"]["config5_mcts_4096_leaves"]
+    for k in ("hipgraph_serial_step_us", "serial_step_us", "two_stream_step_us", "batched_mcts_device_step_hipgraph_us", "batched_mcts_leaves_step_with_d2h_hipgraph_us",
+              "batched_mcts_transfers_us", "batched_mcts_simulate_native_tree_ms", "batched_mcts_simulate_split_us"):
+        assert k in c5, (k, c5)
+    assert set(c5["batched_mcts_simulate_split_us"]) == {"select", "device_and_transfers", "update"}
+    assert c5["batched_mcts_leaves_step_with_d2h_hipgraph_us"] < 260          # round 4: 326 us; round 5: 203-215 us
+    # round 5: the loops the reference actually runs ride in the driver line
+    ap = d["configs"]["adi_pipeline"]
+    for size in ("200x30", "20000x30", "100000x30", "200x30_hipgraph"):
+        assert ap[size]["seconds"] > 0 and ap[size]["samples_per_s"] > 0, ap
+    assert ap["200x30"]["seconds"] < 3e-3 and ap["20000x30"]["samples_per_s"] > 4e6 and ap["100000x30"]["samples_per_s"] > 4e6, ap   # the round-4 review's bars
+    ro = d["configs"]["rollout"]
+    assert all(ro[k]["us_per_timestep"] > 0 for k in ("n300_eager", "n300_hipgraph", "n65536_eager", "n65536_hipgraph")), ro
+    rs = d["configs"]["reset_seeds_1M_k30"]
+    assert rs["envs"] == 1 << 20 and rs["scramble_count"] == 30 and rs["legacy_actions_us"] < 1500 and rs["reset_ms"] < 3.0, rs   # round 4: 3.0 ms of draws
+    for k in ("frac_basis", "frac_timed_region", "frac_wall_clock"):
+        assert k in r, k
+    assert abs(r["frac_timed_region"] - r["algorithmic_bytes_per_launch"] / (r["launch_us_timed_region"] * 1e-6) / 8e12) < 1e-6
+    assert abs(r["frac_wall_clock"] - r["algorithmic_bytes_per_launch"] / (d["ms_per_step"] * 1e-3) / 8e12) < 1e-6 and r["frac_basis"].startswith("launch_us")
     # the facade must stay FASTER than the reference's own batch-1 step (24.6 us on one core; 11-12 us measured
     # here on an idle box).  Wall-clock on a shared host: the best of five 1100-step batches gates, the median only a gross regression
     fb = d["configs"]["facade_batch1"]
@@ -82,11 +100,14 @@ def test_bench_json_line():
     pc = {x["name"]: x for x in r["per_config"]}
     for name in ("cfg2 1M step+reward", "4M step in place", "4M step+reward", "4M step+reward+code", "16M step (HBM only)",
                  "1M step+dense f32", "1M step+dense bf16", "1M code->dense f32", "1M code->dense bf16", "1M expansion",
-                 "cfg3 ADI 100k x 30", "ADI 100k x 30 codes", "ADI 100k x 30 family"):
+                 "cfg3 ADI 100k x 30", "ADI 100k x 30 codes", "ADI 100k x 30 family", "1M code->dense f16", "1M code->dense u8", "1M step+dense u8",
+                 "2x2x2 1M expansion", "2x2x2 1M code->dense f32", "ADI dense blocks f32 43008x1", "ADI dense blocks f32 20000x2", "ADI dense blocks bf16 43008x2"):
         x = pc[name]
         assert x["kernel"].startswith("k_") and abs(x["frac"] - x["bytes"] / (x["launch_us"] * 1e-6) / 8e12) < 2e-3, name
     assert len(r["per_config"]) == len(recs)
-    # the family record halves the code-emitting ADI launch (118 B per (walk, depth) instead of 327 B; round-3 review: <= 110 us)
+    assert pc["ADI dense blocks f32 43008x1"]["frac"] > 0.65 and pc["ADI dense blocks f32 43008x1"]["kernel"].startswith("k_code_to_dense_front<Cube3,f32,F=1,gather,family>")
+    assert [x for x in recs if x["short"] == "ADI 100k x 30 family"][0]["roofline"]["bytes_per_unit"] == 64
+    # the family record halves the code-emitting ADI launch (64 B per (walk, depth) instead of 327 B; round-3 review: <= 110 us)
     assert pc["ADI 100k x 30 family"]["launch_us"] < 110 and pc["ADI 100k x 30 family"]["launch_us"] < 0.7 * pc["ADI 100k x 30 codes"]["launch_us"]
 
 

@@ -160,7 +160,9 @@ def run(short=False, iters=None, sims=20):
 
 
 def rounded(res):
-    return {k: (round(v, 2) if isinstance(v, float) else {a: round(b, 2) for a, b in v.items()} if isinstance(v, dict) else v) for k, v in res.items()}
+    def r(v):
+        return round(v, 2) if isinstance(v, float) else {a: r(b) for a, b in v.items()} if isinstance(v, dict) else [r(x) for x in v] if isinstance(v, list) else v
+    return {k: r(v) for k, v in res.items()}
 
 
 def main():

@@ -12,12 +12,14 @@
 //   k_code_to_dense_front   the same for large 3x3x3 batches: ONE 3840-byte pass per workgroup, one write front per XCD (the
 //                     shape of a fill kernel: 0.85-0.94 of the HBM peak wherever the buffer lives); also expands the ADI
 //                     family record to its 13 dense blocks; second launch of rc_apply_moves_ws / rc_encode_ws
-//   k_scramble        reset()'s scramble loop, in place    cube_env.py:65-67
-//   k_legacy_actions  numpy's legacy MT19937 draws of reset(seed, k), one env per lane    cube_env.py:62-65
+//   k_scramble        reset()'s scramble loop, in place or out of untouched start states (the lockstep search's replay)    cube_env.py:65-67
+//   k_legacy_actions_stream / k_legacy_actions   numpy's legacy MT19937 draws of reset(seed, k), one env per lane: the first 227 outputs
+//                     from two init_genrand chain iterators in registers, the general form with the state in LDS    cube_env.py:62-65
 //   k_expand          12 children of every cube         cube_env.py:212-236, mcts.py:96-101
 //   k_adi             ADI walks + expansion, persistent over depth, per-walk xoroshiro128+; outputs: stickers, picked codes,
 //                     or the 51-row FAMILY record (the shared look-ups themselves)    cube_env.py:177-194,212-236
-//   k_adi_targets     target value/policy/error         cube_env.py:229-232,239-251
+//   k_adi_targets     target value/policy/error, one depth or a group of depths straight from the net's output    cube_env.py:229-232,239-251
+//   k_search_pack     codes + flags of one expansion laid out per root for the host trees of a lockstep search    mcts.py:96-101
 //   k_facade_step     CubeEnv.step / a whole move list for ONE cube, results into host-mapped memory
 //   k_facade_expand   key + 12 child keys + solved flags (+ dense one-hots) of ONE cube    mcts.py:83-113
 //   k_read_status     atomic read-and-clear of the per-device status word

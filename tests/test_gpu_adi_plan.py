@@ -336,3 +336,149 @@ def test_scramble_from_pinned_paths_and_search_pack(ops, L, oracle, cs):
         ops.scramble(work, n, cs, depth, actions_in=host[:depth], src=roots[:1])
     with pytest.raises(L.RubikHipError):
         ops.search_pack(code, ex["child_code"], ex["child_solved"], n, cs, leaf, child[:, :3], solved)
+
+
+def test_workspace_cache_is_locked_bounded_and_releasable(ops, L, oracle):
+    """two host threads driving ONE stream through the workspace route (step + code, then the front writer) get their own
+    results -- the cache look-up and both launches of a call are one critical section -- and the cache keeps at most _WS_MAX entries."""
+    import threading
+    n, cs = (1 << 17) + 3, 3
+    rng = np.random.default_rng(5)
+    jobs = []
+    for t in range(2):
+        st = oracle.adi(cs, n, 5, seed=40 + t, stream=t, want_children=False, threads=4)["parents"][:, -1]
+        acts = rng.integers(0, 12, n, dtype=np.uint8)
+        jobs.append((st, acts, ops.from_aos(st, "cuda"), torch.from_numpy(acts).cuda(), torch.empty((n, 20, 24), dtype=torch.float32, device="cuda")))
+    errors = []
+
+    def work(job):
+        try:
+            _, _, src, a_d, oh = job
+            dst = torch.empty_like(src)
+            for _ in range(25):
+                ops.apply_moves(src, dst, a_d, n, cs, None, None, oh, L.FMT_F32)
+        except Exception as e:                                        # surfaced below: a thread must not die silently
+            errors.append(e)
+    ops.release_workspaces()
+    threads = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for st, acts, _, _, oh in jobs:
+        _, e_code, _, _ = oracle.step(cs, st, acts, threads=4)
+        assert (oh.argmax(-1).cpu().numpy() == e_code).all() and float(oh.sum()) == n * 20
+    assert len(ops._workspaces) == 1                                  # one stream, one workspace
+    streams = [torch.cuda.Stream() for _ in range(ops._WS_MAX + 3)]
+    _, _, src, a_d, oh = jobs[0]
+    dst = torch.empty_like(src)
+    torch.cuda.synchronize()
+    for s in streams:
+        with torch.cuda.stream(s):
+            ops.apply_moves(src, dst, a_d, n, cs, None, None, oh, L.FMT_F32)
+        s.synchronize()
+    assert len(ops._workspaces) == ops._WS_MAX
+    ops.release_workspaces()
+    assert len(ops._workspaces) == 0
+
+
+def test_cube_env_keeps_its_adi_plan_and_replays_it_as_a_graph(oracle):
+    """CubeEnv.get_random_samples (cube_env.py:177-194) called epoch after epoch with one shape (train.py:152-155): the plan's buffers are
+    kept between calls, with env.adi_graph the captured hipGraph is replayed, the samples are those of the eager env for the same
+    numpy seed, the global generator ends where the reference leaves it, and the env sits on the last walk's final state."""
+    import rubiks_cube_solver_amd as rc
+    model, w, b = _linear_model(3)
+    envs = [rc.make_env(torch.device("cuda"), 3) for _ in range(2)]
+    envs[1].adi_graph = True
+    bufs = [rc.TensorReplayBuffer(10_000, 512, 3), rc.TensorReplayBuffer(10_000, 512, 3)]
+    states = []
+    for env, buf in zip(envs, bufs):
+        np.random.seed(77)
+        for epoch in range(3):
+            env.get_random_samples(buf, model, 12, 50, 0.5)
+        states.append(np.random.get_state()[1].copy())
+        assert len(env._adi_plans) == 1 and buf.size == 3 * 50 * 12
+    assert (states[0] == states[1]).all()
+    plan = next(iter(envs[1]._adi_plans.values()))
+    assert plan.graph and len(plan._graphs) == 1 and not next(iter(envs[0]._adi_plans.values())).graph
+    for k in ("code", "target_policy", "scramble_count"):
+        assert torch.equal(getattr(bufs[0], k), getattr(bufs[1], k)), k
+    assert torch.allclose(bufs[0].target_value, bufs[1].target_value, atol=1e-6) and np.allclose(bufs[0].error_memory, bufs[1].error_memory, atol=1e-6)
+    # the samples themselves, against the oracle: the third epoch's draws
+    np.random.seed(77)
+    for _ in range(2 * 50):
+        np.random.randint(12, size=12)
+    acts = np.stack([np.random.randint(12, size=12) for _ in range(50)]).astype(np.uint8)
+    exp, tv, tp, tie, err = _expected(oracle, 3, 50, 12, 0.5, w, b, actions_in=acts)
+    last = slice(2 * 600, 3 * 600)
+    assert (bufs[1].code[last].cpu().numpy().reshape(50, 12, 20) == exp["parent_code"]).all()
+    assert np.allclose(bufs[1].target_value[last].cpu().numpy().reshape(50, 12), tv, atol=2e-5)
+    assert np.allclose(bufs[1].error_memory[last].reshape(50, 12), err, atol=2e-5)
+    from oracle.oracle_np import OracleCubeEnv
+    ref = OracleCubeEnv(None, 3)
+    for a in acts[-1]:
+        ref.step(int(a))
+    assert (envs[1].sim_cube == ref.sim_cube).all() and (envs[0].sim_cube == ref.sim_cube).all()
+    other = torch.nn.Linear(480, 1).cuda()                             # another model object: the cached plan is dropped, not reused
+
+    def model2(x):
+        return other(x.reshape(x.shape[0], -1).float()), torch.zeros(x.shape[0], 12, device=x.device)
+    envs[1].get_random_samples(bufs[1], model2, 12, 50, 0.5)
+    assert len(envs[1]._adi_plans) == 1 and next(iter(envs[1]._adi_plans.values())).model is model2
+    for e in envs:
+        e.close()
+
+
+def test_round5_entry_points_random_shapes(ops, L, oracle):
+    """A bounded fuzz over the round-5 launches: random walk counts around the tile / pack / pass boundaries, depth groups, block
+    strides and formats for the family block writer and the grouped target rule (against the oracle's codes and a numpy restatement of
+    cube_env.py:229-251), random seeds and counts for both generator forms (against numpy)."""
+    rng = np.random.default_rng(2025)
+    dts = (torch.float32, torch.bfloat16, torch.float16, torch.uint8)
+    for case in range(24):
+        n = int(rng.choice([1, 2, 7, 8, 9, 63, 255, 256, 257, 1023, 1025, 4097, 16383, 16384, 16385, 33000]))
+        D = int(rng.integers(1, 6))
+        bs = n + int(rng.choice([0, 1, 7, 8, 100]))
+        pitch, bufs = ops.adi_buffers(n, D, 3, "cuda", family=True)
+        ops.adi_generate(n, D, 3, pitch, "cuda", seed=case, stream_id=9, **bufs)
+        exp = oracle.adi(3, n, D, seed=case, stream=9, want_children=False, threads=4)
+        dt = dts[case % 4]
+        g0 = int(rng.integers(0, D))
+        gd = D - g0
+        blocks = torch.zeros((gd * 13 * bs, 20, 24), dtype=dt, device="cuda")
+        ops.onehot_from_family(bufs["family"][g0:], n, 3, blocks, block_stride=bs, n_depths=gd)
+        v = blocks.view(gd, 13, bs, 20, 24)
+        got = v[:, :, :n].float().argmax(-1).cpu().numpy()
+        assert (got[:, 12].transpose(1, 0, 2) == exp["parent_code"][:, g0:]).all(), (case, n, D, bs, dt)
+        assert (got[:, :12].transpose(2, 0, 1, 3) == exp["child_code"][:, g0:]).all(), (case, n, D, bs, dt)
+        assert float(v[:, :, :n].float().sum()) == gd * 13 * n * 20 and float(v[:, :, n:].float().abs().sum()) == 0    # one 1 per row, pad rows untouched
+        vals = torch.randn(gd * 13 * bs, device="cuda")
+        wgt = torch.rand(gd, dtype=torch.float64, device="cuda") + 0.1
+        tv = torch.zeros((n, D), dtype=torch.float32, device="cuda")
+        tp = torch.zeros((n, D), dtype=torch.int32, device="cuda")
+        er = torch.zeros((n, D), dtype=torch.float64, device="cuda")
+        ops.adi_targets_depths(vals, 13 * bs, bs, bufs["child_solved"][g0:], vals[12 * bs:], 13 * bs, wgt, n, gd, 3, tv[:, g0:], tp[:, g0:], er[:, g0:])
+        vv = vals.view(gd, 13, bs)[:, :, :n].cpu().numpy()
+        solved = exp["child_solved"][:, g0:].astype(bool)                                   # [n, gd, 12]
+        cv = vv[:, :12].transpose(2, 0, 1) + np.float32(-1.0)
+        want_tv = np.where(solved.any(-1), np.float32(1.0), cv.max(-1))
+        want_tp = np.where(solved.any(-1), solved.argmax(-1), cv.argmax(-1))
+        assert (tv[:, g0:].cpu().numpy() == want_tv).all() and (tp[:, g0:].cpu().numpy() == want_tp).all(), (case, n, D)
+        want_er = np.abs(vv[:, 12].T.astype(np.float64) - want_tv.astype(np.float64)) * wgt.cpu().numpy()[None, :]
+        assert (er[:, g0:].cpu().numpy() == want_er).all() and float(tv[:, :g0].abs().sum()) == 0
+    for case in range(12):
+        cs = 3 if case % 2 else 2
+        A = 12 if cs == 3 else 6
+        n = int(rng.choice([1, 63, 64, 65, 255, 257, 1000, 4099]))
+        seeds = rng.integers(0, 2 ** 32, n, dtype=np.uint64)
+        kmax = int(rng.choice([1, 2, 30, 64, 129, 260]))
+        ks = rng.integers(0, kmax + 1, n)
+        ks[0] = kmax
+        want = _numpy_legacy(seeds, ks, A)
+        variant = [0, 1, 2, 2 + 16 * int(rng.integers(1, 228))][case % 4]
+        buf, kk = ops.legacy_scramble_actions(torch.from_numpy(seeds.astype(np.int64)), cs, ks.tolist(), device="cuda", variant=variant)
+        got = buf.cpu().numpy()
+        for i in range(n):
+            assert (got[:ks[i], i] == want[i]).all() and (got[ks[i]:kk, i] == A).all(), (case, cs, n, kmax, variant, i)

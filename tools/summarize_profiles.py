@@ -38,7 +38,7 @@ def first(pattern):
     return f[0] if f else None
 
 
-for name in ("bench", "cfg5", "rollout", "facade", "adi_pipeline"):
+for name in ("bench", "cfg5", "rollout", "facade"):      # (adi_pipeline: profiles/rNN_adi_pipeline.json is the trace split, written by hand)
     src = os.path.join(G, f"{tag}_{name}.json")
     if os.path.exists(src) and os.path.getsize(src):
         lines = [l for l in open(src).read().splitlines() if l.startswith("{")]
@@ -82,6 +82,11 @@ if fresh:
 def read_pmc(names):
     out = {}
     for name in names:
+        agg_file = os.path.join(G, f"{tag}_prof_{name}", "pmc_aggregate.json")     # reduced on the GPU box by tools/pmc_aggregate.py
+        if os.path.exists(agg_file):
+            for k, v in json.load(open(agg_file)).items():
+                out.setdefault(k, {}).update({c: {"mean": x["mean"], "launches": x["launches"]} for c, x in v.items()})
+            continue
         for f in glob.glob(os.path.join(G, f"{tag}_prof_{name}", "**", "*_counter_collection.csv"), recursive=True):
             agg = collections.defaultdict(list)
             for r in csv.DictReader(open(f)):

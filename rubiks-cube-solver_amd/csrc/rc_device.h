@@ -717,10 +717,57 @@ __device__ __forceinline__ void dense_write_333(const uint8_t *lds_code, int tp,
     else sweep(std::false_type{});
 }
 
+// 2x2x2 fast path (320-thread workgroups).  147 elements per cube are not a whole number of 16-byte chunks, but EPT cubes are exactly
+// 147 chunks: a PASS = 4 / 8 / 16 whole cubes (f32 / 16-bit / u8) = 2352 bytes.  Threads 0..146 write one pass, 147..293 the next
+// (294 of 320 lanes busy), and a thread always writes the same chunk of its pass -- which cube of the pass, which slot's code and which
+// value make each of its elements a 1 (row = piece, column = slot * 3 + orientation, cube_env.py:143-147) is fixed before the loop,
+// so an element costs one LDS byte read and one compare.  The generic loop below re-derives cube / piece / slot / orientation with four
+// divisions PER ELEMENT: 1M cubes ran at 0.66 (f32), 0.45 (16-bit), 0.23 (u8) of the HBM peak, falling with the element size --
+// instruction-bound, not store-bound (profiles/r05_dense222.json).
+template <class T, class E, int NT>
+__device__ __forceinline__ void dense_write_222(const uint8_t *lds_code, int tp, E *out, int ncubes, int tid) {
+    static_assert(T::SIZE == 2 && T::R * T::C == 147);
+    constexpr int EPT = 16 / (int)sizeof(E), CPP = EPT, NCH = 147, PPI = NT / NCH;   // CPP cubes * 147 elements = NCH chunks; PPI passes per round
+    static_assert(PPI >= 1);
+    const int q = tid / NCH, t = tid - q * NCH;                                    // pass of the round, chunk of the pass
+    if (q >= PPI) return;
+    uint32_t off[EPT], want[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const uint32_t g = (uint32_t)t * EPT + j, c = g / 147u, e = g - c * 147u;
+        const uint32_t piece = e / 21u, rem = e - piece * 21u, slot = rem / 3u, ori = rem - slot * 3u;
+        off[j] = slot * (uint32_t)tp + c + (uint32_t)q * CPP;                      // LDS byte of that cube's code of `slot`, relative to the round
+        want[j] = piece * 3u + ori;                                               // the code that puts the 1 on this element
+    }
+    const uint32_t total = (uint32_t)ncubes * 147u;
+    const __amdgpu_buffer_rsrc_t srd = make_srd(out);                             // `out` is workgroup-uniform
+    for (int base = 0; base + q * CPP < ncubes; base += CPP * PPI) {              // (cubes past ncubes: stale but in-bounds tile bytes, never stored)
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const uint32_t one = (uint32_t)lds_code[off[j] + base] == want[j] ? One<E>::v : 0u;
+            w[j * (int)sizeof(E) / 4] |= one << (8 * ((j * (int)sizeof(E)) & 3));
+        }
+        const uint32_t e0 = (uint32_t)(base + q * CPP) * 147u + (uint32_t)t * EPT;
+        if (e0 + EPT <= total) {
+            Pk<4> u;
+            u.d[0] = w[0]; u.d[1] = w[1]; u.d[2] = w[2]; u.d[3] = w[3];
+            bst<4, kAuxStreamStore>(srd, e0 * (uint32_t)sizeof(E), 0, u);
+        } else {                                                                  // ragged end of the last pass
+            for (uint32_t j = 0; e0 + j < total; ++j) {
+                const uint32_t bit = j * (uint32_t)sizeof(E) * 8u;
+                out[e0 + j] = __builtin_bit_cast(E, (typename UIntOf<sizeof(E)>::type)(w[bit >> 5] >> (bit & 31u)));
+            }
+        }
+    }
+}
+
 template <class T, class E>
 __device__ __forceinline__ void dense_write(const uint8_t *lds_code, int tp, E *out, int ncubes, int tid, int nthreads) {
     if constexpr (T::SIZE == 3) {
         if (nthreads == 256) { dense_write_333<T, E>(lds_code, tp, out, ncubes, tid); return; }
+    } else {
+        if (nthreads == 320) { dense_write_222<T, E, 320>(lds_code, tp, out, ncubes, tid); return; }
     }
     constexpr int EPT = 16 / (int)sizeof(E);  // elements per 16-byte store
     const uint32_t total = (uint32_t)ncubes * T::R * T::C;

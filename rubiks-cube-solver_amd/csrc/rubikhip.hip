@@ -203,6 +203,10 @@ __global__ void __launch_bounds__(BLOCK) k_step(StepArgs a) {
 
 // ----------------------------------------------------------- step + dense one-hot (LDS stage)
 constexpr int kDenseBlock = 256;
+// 2x2x2, 1- and 2-byte elements: 320 threads -- the dense writer's unit is a 147-chunk pass (dense_write_222) and 294 of 320 lanes cover
+// two of them per round.  f32 keeps the generic 256-thread loop: it is store-bound there (0.66 against 0.54 with the pass form at 1M
+// cubes), the narrow formats are instruction-bound in it (0.45 / 0.23 against 0.53 / 0.52; profiles/r05_dense222.json).
+template <class T, class E> constexpr int kDenseThreads = (T::SIZE == 2 && sizeof(E) <= 2) ? 320 : kDenseBlock;
 // TILE cubes per workgroup (64 | 256): the first TILE/4 lanes compute the pack's codes, then
 // all 256 threads stream the dense rows.  Small tiles keep small batches (MCTS leaves) spread over
 // the chip: 4096 cubes are 64 workgroups at TILE = 64 but only 4 at TILE = 1024.
@@ -245,7 +249,7 @@ __device__ __forceinline__ void dense_produce(const StepArgs &a, int64_t tile0, 
 }
 
 template <class T, class E, bool MOVE, bool STORE, int TILE>
-__global__ void __launch_bounds__(kDenseBlock) k_step_dense(StepArgs a, E *dense) {
+__global__ void __launch_bounds__((kDenseThreads<T, E>)) k_step_dense(StepArgs a, E *dense) {
     constexpr int TP = TILE + 4;
     __shared__ __attribute__((aligned(16))) uint8_t lds_code[T::SLOTS * TP];
     const uint32_t lo = threadIdx.x * 4;
@@ -257,7 +261,7 @@ __global__ void __launch_bounds__(kDenseBlock) k_step_dense(StepArgs a, E *dense
 #endif
         const int64_t left = a.n - tile0;
         const int ncubes = left < TILE ? (int)left : TILE;
-        dense_write<T, E>(lds_code, TP, dense + tile0 * (T::R * T::C), ncubes, threadIdx.x, kDenseBlock);
+        dense_write<T, E>(lds_code, TP, dense + tile0 * (T::R * T::C), ncubes, threadIdx.x, kDenseThreads<T, E>);
 #if RC_DENSE_CTRL < 2
         __syncthreads();                                               // the code tile is reused by the next iteration
 #endif
@@ -265,7 +269,7 @@ __global__ void __launch_bounds__(kDenseBlock) k_step_dense(StepArgs a, E *dense
 }
 
 template <class T, class E, int TILE>
-__global__ void __launch_bounds__(kDenseBlock) k_code_to_dense(const uint8_t *code, int64_t n, int64_t code_pitch, int shift, E *dense) {
+__global__ void __launch_bounds__((kDenseThreads<T, E>)) k_code_to_dense(const uint8_t *code, int64_t n, int64_t code_pitch, int shift, E *dense) {
     constexpr int TP = TILE + 4;
     __shared__ __attribute__((aligned(16))) uint8_t lds_code[T::SLOTS * TP];
     const uint32_t lo = threadIdx.x * 4;
@@ -281,7 +285,7 @@ __global__ void __launch_bounds__(kDenseBlock) k_code_to_dense(const uint8_t *co
 #endif
         const int64_t left = n - tile0;
         const int ncubes = left < TILE ? (int)left : TILE;
-        dense_write<T, E>(lds_code, TP, dense + tile0 * (T::R * T::C), ncubes, threadIdx.x, kDenseBlock);
+        dense_write<T, E>(lds_code, TP, dense + tile0 * (T::R * T::C), ncubes, threadIdx.x, kDenseThreads<T, E>);
 #if RC_DENSE_CTRL < 2
         __syncthreads();
 #endif
@@ -1288,7 +1292,8 @@ inline DenseForm dense_form(int64_t n, int variant, bool fused, int fmt) {
     //                  64-cube tiles from 2^19 (0.78-0.80 against 0.73-0.76), 256-cube tiles otherwise
     if (!fused && wide_ok && n >= ((int64_t)1 << (fmt == RC_FMT_F32 ? 15 : fmt == RC_FMT_U8 ? 18 : 16))) return kDenseFront;
     if (n < ((int64_t)1 << 17) || (!fused && wide_ok)) return kDense64;
-    if (!fused) return kDense256;
+    if (!fused) return T::SIZE == 2 && fmt != RC_FMT_U8 ? kDense64 : kDense256;    // 2x2x2 code -> dense (profiles/r05_dense222.json): 64-cube tiles for
+    //   f32 (0.66 against 0.58 at 1M cubes) and the 16-bit formats (0.53 against 0.48), 256-cube tiles for u8 (0.52 against 0.34)
     return T::SIZE == 3 && (fmt == RC_FMT_F16 || fmt == RC_FMT_BF16) && n >= ((int64_t)1 << 19) ? kDense64 : kDense256;
 }
 struct WideGrid { int64_t groups, per; };
@@ -1311,11 +1316,11 @@ int launch_dense_t(const StepArgs &a, void *onehot, int fmt, hipStream_t st) {
     int64_t blocks = (a.n + TILE - 1) / TILE;
     RC_GRID(blocks);
     blocks = dense_grid(blocks, fmt);
-    const dim3 g((unsigned)blocks), b(kDenseBlock);
-    if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_step_dense<T, uint8_t, MOVE, STORE, TILE>), g, b, 0, st, a, static_cast<uint8_t *>(onehot));
-    else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_step_dense<T, uint16_t, MOVE, STORE, TILE>), g, b, 0, st, a, static_cast<uint16_t *>(onehot));
-    else if (fmt == RC_FMT_BF16) hipLaunchKernelGGL((k_step_dense<T, Bf16, MOVE, STORE, TILE>), g, b, 0, st, a, static_cast<Bf16 *>(onehot));
-    else hipLaunchKernelGGL((k_step_dense<T, float, MOVE, STORE, TILE>), g, b, 0, st, a, static_cast<float *>(onehot));
+    const dim3 g((unsigned)blocks);
+    if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_step_dense<T, uint8_t, MOVE, STORE, TILE>), g, dim3(kDenseThreads<T, uint8_t>), 0, st, a, static_cast<uint8_t *>(onehot));
+    else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_step_dense<T, uint16_t, MOVE, STORE, TILE>), g, dim3(kDenseThreads<T, uint16_t>), 0, st, a, static_cast<uint16_t *>(onehot));
+    else if (fmt == RC_FMT_BF16) hipLaunchKernelGGL((k_step_dense<T, Bf16, MOVE, STORE, TILE>), g, dim3(kDenseThreads<T, Bf16>), 0, st, a, static_cast<Bf16 *>(onehot));
+    else hipLaunchKernelGGL((k_step_dense<T, float, MOVE, STORE, TILE>), g, dim3(kDenseThreads<T, float>), 0, st, a, static_cast<float *>(onehot));
     RC_HIP(hipGetLastError());
     return RC_OK;
 }
@@ -1333,11 +1338,11 @@ int launch_code_to_dense(const uint8_t *code, int64_t n, int64_t code_pitch, int
     int64_t blocks = (n + TILE - 1) / TILE;
     RC_GRID(blocks);
     blocks = dense_grid(blocks, fmt);
-    const dim3 g((unsigned)blocks), b(kDenseBlock);
-    if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_code_to_dense<T, uint8_t, TILE>), g, b, 0, st, code, n, code_pitch, sh, static_cast<uint8_t *>(onehot));
-    else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_code_to_dense<T, uint16_t, TILE>), g, b, 0, st, code, n, code_pitch, sh, static_cast<uint16_t *>(onehot));
-    else if (fmt == RC_FMT_BF16) hipLaunchKernelGGL((k_code_to_dense<T, Bf16, TILE>), g, b, 0, st, code, n, code_pitch, sh, static_cast<Bf16 *>(onehot));
-    else hipLaunchKernelGGL((k_code_to_dense<T, float, TILE>), g, b, 0, st, code, n, code_pitch, sh, static_cast<float *>(onehot));
+    const dim3 g((unsigned)blocks);
+    if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_code_to_dense<T, uint8_t, TILE>), g, dim3(kDenseThreads<T, uint8_t>), 0, st, code, n, code_pitch, sh, static_cast<uint8_t *>(onehot));
+    else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_code_to_dense<T, uint16_t, TILE>), g, dim3(kDenseThreads<T, uint16_t>), 0, st, code, n, code_pitch, sh, static_cast<uint16_t *>(onehot));
+    else if (fmt == RC_FMT_BF16) hipLaunchKernelGGL((k_code_to_dense<T, Bf16, TILE>), g, dim3(kDenseThreads<T, Bf16>), 0, st, code, n, code_pitch, sh, static_cast<Bf16 *>(onehot));
+    else hipLaunchKernelGGL((k_code_to_dense<T, float, TILE>), g, dim3(kDenseThreads<T, float>), 0, st, code, n, code_pitch, sh, static_cast<float *>(onehot));
     RC_HIP(hipGetLastError());
     return RC_OK;
 }
@@ -2115,7 +2120,7 @@ int rc_describe_dispatch(int op, int cube_size, int64_t n, int depth, unsigned o
                 }
                 const int form = (int)dense_form<T>(n, variant, true, fmt);
                 snprintf(buf, buflen, "k_step_dense<%s,%s,%s,TILE=%d> grid=%lld block=%d", cube, names[fmt], states ? "move,store" : "encode",
-                         form, (long long)dense_grid((n + form - 1) / form, fmt), kDenseBlock);
+                         form, (long long)dense_grid((n + form - 1) / form, fmt), fmt == RC_FMT_F32 ? kDenseThreads<T, float> : kDenseThreads<T, uint8_t>);
                 return RC_OK;
             }
             const bool with_code = code || fmt == RC_FMT_CODE;
@@ -2137,7 +2142,7 @@ int rc_describe_dispatch(int op, int cube_size, int64_t n, int depth, unsigned o
                 const WideGrid w = wide_grid(n, variant);
                 snprintf(buf, buflen, "k_code_to_dense_wide<%s,%s> tiles_per_group=%lld grid=%lld block=%d", cube, names[fmt], (long long)w.per, (long long)w.groups, kWideBlock);
             } else {
-                snprintf(buf, buflen, "k_code_to_dense<%s,%s,TILE=%d> grid=%lld block=%d", cube, names[fmt], (int)form, (long long)dense_grid((n + (int)form - 1) / (int)form, fmt), kDenseBlock);
+                snprintf(buf, buflen, "k_code_to_dense<%s,%s,TILE=%d> grid=%lld block=%d", cube, names[fmt], (int)form, (long long)dense_grid((n + (int)form - 1) / (int)form, fmt), fmt == RC_FMT_F32 ? kDenseThreads<T, float> : kDenseThreads<T, uint8_t>);
             }
             return RC_OK;
         }

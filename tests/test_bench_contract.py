@@ -187,13 +187,14 @@ GPU_PROCESS_LIMIT = 6     # this pool's process guard: at most 6 processes of on
 
 @pytest.mark.gpu
 def test_bench_many_ranks_rehearsal(oracle):
-    """BASELINE config 4 is 8 ranks x 1M cubes.  With one GPU and a guard of 6 GPU processes per job (this pytest process is one of
-    them) the closest rehearsal is FIVE ranks x 1M cubes sharing the GPU over gloo, --no-configs: five distinct stream_ids, five
+    """BASELINE config 4 is 8 ranks x 1M cubes.  With one GPU and a guard of 6 GPU processes per job -- of which this pytest process
+    is one once any in-process GPU test has run, and the launcher another (round 5: 5 ranks + launcher + a pytest process that already
+    held the GPU = 7 = a killed run) -- the rehearsal is FOUR ranks x 1M cubes sharing the GPU over gloo, --no-configs: distinct stream_ids,
     oracle-matching shas, the aggregate keys of the N > 1 line.  `bench.py --gpus 8 --cubes-per-gpu 1048576` under the driver's
     launcher is this same code path with backend nccl (exercised at world size 1 above).  Eight streams against the oracle without
     a GPU: tests/test_host_logic.py::test_eight_rank_streams_and_shards."""
     import hashlib
-    ranks = GPU_PROCESS_LIMIT - 1
+    ranks = GPU_PROCESS_LIMIT - 2
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
            "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "20", "--warmup", "3",

@@ -172,7 +172,9 @@ def test_dispatch_description_and_enodev_without_gpu():
     assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 20, fmt=L.FMT_BF16).startswith("k_code_to_dense_front<Cube3,bf16,F=1,lds> cubes_per_pass=4 xcd grid=262144")
     assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 20, fmt=L.FMT_U8).startswith("k_code_to_dense_front<Cube3,u8,F=2,lds> cubes_per_pass=8 xcd grid=65536")
     assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 20, fmt=L.FMT_BF16, variant=20).startswith("k_code_to_dense_front<Cube3,bf16,F=1,lds> cubes_per_pass=4 grid=262144")
-    assert L.describe(L.OP_CODE_TO_DENSE, 2, 1 << 20, fmt=L.FMT_F32).startswith("k_code_to_dense<Cube2,f32,TILE=256>")
+    assert L.describe(L.OP_CODE_TO_DENSE, 2, 1 << 20, fmt=L.FMT_F32).startswith("k_code_to_dense<Cube2,f32,TILE=64> grid=2048 block=256")
+    assert L.describe(L.OP_CODE_TO_DENSE, 2, 1 << 20, fmt=L.FMT_BF16).startswith("k_code_to_dense<Cube2,bf16,TILE=64> grid=16384 block=320")   # the 147-chunk pass writer
+    assert L.describe(L.OP_CODE_TO_DENSE, 2, 1 << 20, fmt=L.FMT_U8).startswith("k_code_to_dense<Cube2,u8,TILE=256> grid=4096 block=320")
     # thresholds of the front writer: 2^15 (f32), 2^16 (16-bit), 2^18 (u8); 64-cube tiles below
     assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 14, fmt=L.FMT_F32).startswith("k_code_to_dense<Cube3,f32,TILE=64> grid=256")
     assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 15, fmt=L.FMT_F32).startswith("k_code_to_dense_front<Cube3,f32,F=1,gather>")
@@ -540,7 +542,7 @@ def test_eight_rank_streams_and_shards(tmp_path):
     """BASELINE config 4's world size (8 ranks) on CPU over gloo: eight contiguous shards that tile the batch, eight RNG streams
     that are each the oracle's (seed, stream_id = rank) stream and pairwise different, SUM / MAX reductions over all eight.
     (A GPU box of this pool admits at most 6 GPU processes per job, so the 8-rank shape is rehearsed here and the kernels' side
-    with 5 ranks in tests/test_bench_contract.py::test_bench_many_ranks_rehearsal.)"""
+    with 4 ranks in tests/test_bench_contract.py::test_bench_many_ranks_rehearsal.)"""
     from oracle.oracle_np import Oracle
     from rubiks_cube_solver_amd import dist as d
     rs = _run_gloo_ranks(tmp_path, 8)

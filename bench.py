@@ -24,8 +24,13 @@ the headline's timed region with HIP events on the launch stream (median of 3 ba
 (kernel = what the library's own dispatch reports, algorithmic bytes per launch, achieved GB/s, fraction of the 8 TB/s HBM peak):
 config 2 (1M cubes, move + reward + done), the 4M step in place, with the reward, with the fused compact code, the 16M-cube step
 whose 1.8 GB ping-pong defeats the Infinity Cache (the HBM-only point: roofline.frac_hbm_only), the fused dense one-hot (f32 /
-bf16), code -> dense (f32 / bf16), config 3 (ADI 100k walks x 30, 715 B per (walk, depth)), the 1M-parent expansion, config 5
-(us per MCTS step, eager and as a hipGraph) and the batch-1 facade latency.  --no-configs skips them.
+bf16 / u8), code -> dense (f32 / bf16 / f16 / u8), 2x2x2 step / expansion / dense, config 3 (ADI 100k walks x 30, 715 B per (walk,
+depth)) and its code / family forms, the family -> dense-block launch of the ADI pipeline, the 1M-parent expansion.  Then the loops
+the reference actually runs, end to end on the host clock: `adi_pipeline` (get_random_samples batched: 200 x 30 = the reference's
+own size, 20k x 30, 100k x 30, and the hipGraph replay), `config5_mcts_4096_leaves` (config 5: us per MCTS step eager / hipGraph /
+two streams, the lockstep search's device step + transfers and whole simulations split select / device / update), `rollout`
+(greedy validation rollouts), `reset_seeds_1M_k30` (reset(seed, 30) for 1M envs, numpy's legacy generator on the device) and the
+batch-1 facade latency.  --no-configs skips them.  RC_BENCH_DRY=1 (with --backend gloo) runs the N-rank plumbing without a GPU.
 """
 import argparse
 import json
@@ -138,7 +143,7 @@ def cpu_baseline(budget_s=8.0):
 
 
 def other_configs(torch, ops, _lib, dev, acts):
-    """BASELINE.json configs 2, 3, 5 and the fused-output variants, each with its own roofline sub-record.
+    """BASELINE.json configs 2, 3, 5, the fused-output variants and (pipeline_configs) the end-to-end loops, each with its own record.
     Timed with HIP events on the launch stream, outside the headline's timed region.  `kernel` of every record is what
     rc_describe_dispatch reports for exactly that call (the library's own pick_* functions), never a literal."""
     recs = []
@@ -354,6 +359,7 @@ def pipeline_configs(torch, ops, _lib, dev):
         model = DeepCubeStandIn().to(dev).eval()
         ap = adi_run(reps=3, model=model, dev=dev)
         ap["200x30_hipgraph"] = adi_run(sizes=((200, 30),), reps=5, graph=True, model=model, dev=dev)["200x30"]
+        ap["2x2x2_20000x14"] = adi_run(sizes=((20_000, 14),), reps=3, dev=dev, cube_size=2)["20000x14"]      # the shipped checkpoint's layer sizes (147-512-128-64)
         ap["note"] = ("median wall time of one adi_samples call incl. its final synchronisation; net = random-init DeepCube [1024,256,128] in float32 (the reference's "
                       "config); the reference does 393 samples/s on one CPU core (SURVEY.md section 6)")
         out["adi_pipeline"] = ap

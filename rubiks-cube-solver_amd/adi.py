@@ -95,8 +95,9 @@ class AdiPlan:
             bs = -(-wc // 8) * 8
             return pitch, bs, (self.A + 1) * bs
         # 2x2x2: a depth's A child buffers (and the parents of consecutive depths) are read as ONE tiled code buffer, which needs a
-        # power-of-two pitch >= 512; the block stride is then the padded walk count
-        pitch = max(ops.MIN_TILE, 1 << (wc - 1).bit_length()) if wc <= ops.ADI_TILE else ops.ADI_TILE
+        # power-of-two pitch >= 512; the block stride is then the padded walk count tiles * pitch: take the tile size that pads least
+        # (20 000 walks: 40 tiles of 512 = 20 480 rows per block instead of 2 x 16 384), the larger one on ties
+        pitch = min((1 << lg for lg in range(14, 8, -1)), key=lambda t: -(-max(wc, 1) // t) * t)
         p = ops._tiles_of(wc, pitch) * pitch
         return pitch, p, (self.A + 1) * p
 

@@ -273,8 +273,9 @@ class CubeEnv:
 
     def close(self):
         """Drop the pinned result buffer of the batch-1 entry points and the library's cached device alias of it
-        (rc_facade_release), so that the address can be reused by anyone.  Called on garbage collection too; the env
-        stays usable (the buffer is re-created on the next step)."""
+        (rc_facade_release), so that the address can be reused by anyone, and the plan get_random_samples keeps between calls.
+        Called on garbage collection too; the env stays usable (both are re-created on the next use)."""
+        self._adi_plans.clear()                  # get_random_samples' static buffers (up to the 1 GiB dense budget) and captured graph
         fast, self._fast = self._fast, None
         if fast is not None:
             try:

@@ -63,7 +63,7 @@ def test_bench_json_line():
     assert c5["batched_mcts_leaves_step_with_d2h_hipgraph_us"] < 260          # round 4: 326 us; round 5: 203-215 us
     # round 5: the loops the reference actually runs ride in the driver line
     ap = d["configs"]["adi_pipeline"]
-    for size in ("200x30", "20000x30", "100000x30", "200x30_hipgraph"):
+    for size in ("200x30", "20000x30", "100000x30", "200x30_hipgraph", "2x2x2_20000x14"):
         assert ap[size]["seconds"] > 0 and ap[size]["samples_per_s"] > 0, ap
     assert ap["200x30"]["seconds"] < 3e-3 and ap["20000x30"]["samples_per_s"] > 4e6 and ap["100000x30"]["samples_per_s"] > 4e6, ap   # the round-4 review's bars
     ro = d["configs"]["rollout"]

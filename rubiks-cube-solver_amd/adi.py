@@ -83,7 +83,7 @@ class AdiPlan:
         # zeros once: the pad rows between a block's walks and its stride are never written and must stay finite for the net
         self.dense = torch.zeros((self.group * rows_of(self.chunk) if W and D else 0, self.R, self.C), dtype=self.ddtype, device=dev)
         self.graph = bool(graph)
-        self._graphs = {}
+        self._graphs, self._graph_sig = {}, None
         if self.graph and self.mdev != dev:
             raise ValueError("AdiPlan(graph=True) needs the model on the cubes' device (a host model cannot be captured)")
 
@@ -173,6 +173,10 @@ class AdiPlan:
             if not self.graph:
                 self._after_generate(w0, wc, b)
                 continue
+            sig = _param_addresses(self.model)                 # a captured graph holds the parameters' ADDRESSES: in-place updates
+            if sig != self._graph_sig:                         # (optimizer steps, load_state_dict) are seen, a re-allocation
+                self._graphs.clear()                           # (model.to(...), .half()) is not -- capture again
+                self._graph_sig = sig
             g = self._graphs.get(w0)
             if g is None:                                          # warm-up on a side stream, then capture (as rollout.py does)
                 s = torch.cuda.Stream(dev)
@@ -223,6 +227,13 @@ def release_plans():
 def _lib_status(dev):
     if _lib.read_status(dev) & _lib.STATUS_BAD_ACTION:
         raise IndexError("action out of range")  # cube_env.py:86,96
+
+
+def _param_addresses(model):
+    try:
+        return tuple((prm.data_ptr(), prm.dtype) for prm in model.parameters())
+    except (AttributeError, TypeError):
+        return ()
 
 
 def _module_dtype(model):

@@ -482,3 +482,29 @@ def test_round5_entry_points_random_shapes(ops, L, oracle):
         got = buf.cpu().numpy()
         for i in range(n):
             assert (got[:ks[i], i] == want[i]).all() and (got[ks[i]:kk, i] == A).all(), (case, cs, n, kmax, variant, i)
+
+
+def test_graph_plan_notices_reallocated_parameters():
+    """A captured plan holds the net's parameter ADDRESSES: an in-place update (an optimizer step) is seen by the replay, a re-allocated
+    parameter (model.to / .half / assigning .data) must trigger a new capture, not a replay over the freed tensor."""
+    from rubiks_cube_solver_amd.adi import AdiPlan
+    lin = torch.nn.Linear(480, 1).cuda()
+
+    def model(x):
+        return lin(x.reshape(x.shape[0], -1).float()), torch.zeros(x.shape[0], 12, device=x.device)
+    model.parameters = lin.parameters
+    gp = AdiPlan(model, 3, 300, 5, 0.5, graph=True)
+    ep = AdiPlan(model, 3, 300, 5, 0.5)
+    for step in range(3):
+        a, b = gp.run(seed=step), ep.run(seed=step)
+        assert torch.allclose(a["target_value"], b["target_value"], atol=1e-5) and torch.allclose(a["error"], b["error"], atol=1e-5)
+        with torch.no_grad():
+            lin.weight.add_(0.01 * (step + 1))                                  # in place: same address, the replay reads the new values
+    assert len(gp._graphs) == 1
+    first = next(iter(gp._graphs.values()))
+    gp_before = gp.run(seed=9)["target_value"].clone()
+    lin.weight.data = lin.weight.data.clone() * -1.5                            # a NEW tensor behind the parameter
+    a, b = gp.run(seed=9), ep.run(seed=9)
+    assert torch.allclose(a["target_value"], b["target_value"], atol=1e-5) and torch.allclose(a["error"], b["error"], atol=1e-5)
+    assert float((a["target_value"] - gp_before).abs().max()) > 0.1              # (and the values did change with the weights)
+    assert next(iter(gp._graphs.values())) is not first                         # captured again

@@ -359,6 +359,13 @@ def pipeline_configs(torch, ops, _lib, dev):
         model = DeepCubeStandIn().to(dev).eval()
         ap = adi_run(reps=3, model=model, dev=dev)
         ap["200x30_hipgraph"] = adi_run(sizes=((200, 30),), reps=5, graph=True, model=model, dev=dev)["200x30"]
+        flops_per_state = 2 * (480 * 1024 + 1024 * 256 + 2 * 256 * 128 + 128 * 12 + 128)            # the net's multiply-adds per one-hot state
+        for key in ("200x30", "20000x30", "100000x30", "200x30_hipgraph"):                            # 13 states per sample: 12 children + the parent
+            tf = 13 * ap[key]["samples_per_s"] * flops_per_state / 1e12
+            ap[key]["net_TFLOPs_end_to_end"] = round(tf, 1)
+            ap[key]["frac_of_fp32_mfma_peak"] = round(tf / 157.3, 3)
+        ap["bound"] = ("the caller's value net: 1.64 MFLOP per state in float32 against the 157.3 TFLOP/s fp32 MFMA peak (MI355X_MICROARCH.md); the env kernels are "
+                       "under 5 % of a call (profiles/r05_adi_pipeline.json)")
         ap["2x2x2_20000x14"] = adi_run(sizes=((20_000, 14),), reps=3, dev=dev, cube_size=2)["20000x14"]      # the shipped checkpoint's layer sizes (147-512-128-64)
         ap["note"] = ("median wall time of one adi_samples call incl. its final synchronisation; net = random-init DeepCube [1024,256,128] in float32 (the reference's "
                       "config); the reference does 393 samples/s on one CPU core (SURVEY.md section 6)")

@@ -17,7 +17,7 @@ int main(void) {
     const int64_t n = 5, pitch = 256;
     uint8_t *st, *act, *done, host[54 * 256], hdone[8], hact[16];
     float *reward, hrew[8];
-    if (rc_version() < 400) return 1;
+    if (rc_version() < 500) return 1;
     /* a caller that skips rc_init gets RC_ENODEV, not a raw launch error */
     if (rc_fill_solved((uint8_t *)host, n, pitch, 3, NULL) != RC_ENODEV || strlen(rc_last_error()) == 0) return 16;
     RC(rc_init(0));
@@ -116,6 +116,61 @@ int main(void) {
         if (rc_apply_moves_ws(big, big, bact, m, mp, mp, 3, NULL, bdone, oh_a, RC_FMT_F32, 0, ws + 1, need, NULL) != RC_EINVAL) return 25;   /* misaligned */
         free(ha);
         CK(hipFree(big)); CK(hipFree(bact)); CK(hipFree(bdone)); CK(hipFree(ws)); CK(hipFree(oh_a)); CK(hipFree(oh_b));
+    }
+    /* round-5 entry points from plain C.  (1) reset(seed = 0, 5) draws 5, 0, 3, 11, 3 from both forms of the device generator */
+    {
+        uint32_t *seeds;
+        uint8_t *draws, hd[5 * 256];
+        const uint32_t zero = 0;
+        CK(hipMalloc((void **)&seeds, 16)); CK(hipMalloc((void **)&draws, 5 * 256));
+        CK(hipMemcpy(seeds, &zero, 4, hipMemcpyHostToDevice));
+        const int forms[3] = {0, RC_VARIANT_LEGACY_LDS, RC_VARIANT_LEGACY_STREAM(0)};
+        const uint8_t want[5] = {5, 0, 3, 11, 3};
+        for (int f = 0; f < 3; ++f) {
+            CK(hipMemset(draws, 0xEE, 5 * 256));
+            RC(rc_legacy_scramble_actions_ex(seeds, NULL, 5, 5, 1, 3, draws, 256, NULL, forms[f]));
+            CK(hipMemcpy(hd, draws, 5 * 256, hipMemcpyDeviceToHost));
+            for (int d = 0; d < 5; ++d) if (hd[d * 256] != want[d]) { fprintf(stderr, "legacy draw %d form %d: %d\n", d, f, hd[d * 256]); return 26; }
+        }
+        if (rc_legacy_scramble_actions_ex(seeds, NULL, 5, 5, 1, 3, draws, 256, NULL, 3) != RC_EINVAL) return 27;
+        CK(hipFree(seeds)); CK(hipFree(draws));
+    }
+    /* (2) rc_scramble_from replays R U R' U' that it READS from pinned host memory (rc_host_alias) out of untouched solved cubes;
+     * (3) one expansion + rc_search_pack gives one record per cube; (4) a variant field of another entry point's group is refused */
+    {
+        uint8_t *paths, *alias = NULL, *work, *ccode, *csolved, *lcode, *leaf, *child, *solved, hrec[5 * 12 * 20];
+        CK(hipHostMalloc((void **)&paths, 4 * 256, hipHostMallocMapped));
+        for (int d = 0; d < 4; ++d) memset(paths + d * 256, seq[d], 256);
+        RC(rc_host_alias(paths, (void **)&alias));
+        if (rc_host_alias(hrec, (void **)&alias) != RC_EINVAL) return 28;                       /* plain stack memory is not host-mapped */
+        RC(rc_host_alias(paths, (void **)&alias));
+        CK(hipMalloc((void **)&work, 54 * pitch));
+        RC(rc_fill_solved(st, n, pitch, 3, NULL));
+        RC(rc_scramble_from(st, work, n, pitch, 3, 4, 0, 0, 0, alias, NULL, 256, done, NULL, NULL));
+        CK(hipMemcpy(host, work, 54 * pitch, hipMemcpyDeviceToHost));
+        for (int c = 0; c < n; ++c)
+            for (int s2 = 0; s2 < 54; ++s2)
+                if (host[s2 * pitch + c] != kat[s2] - '0') { fprintf(stderr, "scramble_from mismatch cube %d sticker %d\n", c, s2); return 29; }
+        CK(hipMemcpy(host, st, 54 * pitch, hipMemcpyDeviceToHost));
+        for (int s2 = 0; s2 < 54; ++s2) if (host[s2 * pitch] != s2 / 9) return 30;                /* the source states are untouched */
+        CK(hipMalloc((void **)&ccode, 12 * 20 * pitch)); CK(hipMalloc((void **)&csolved, 12 * pitch)); CK(hipMalloc((void **)&lcode, 20 * pitch));
+        CK(hipMalloc((void **)&leaf, n * 20)); CK(hipMalloc((void **)&child, n * 12 * 20)); CK(hipMalloc((void **)&solved, n * 12));
+        RC(rc_expand_children(st, n, pitch, 3, NULL, csolved, ccode, pitch, NULL));
+        RC(rc_encode(st, n, pitch, 3, lcode, RC_FMT_CODE, pitch, NULL));
+        RC(rc_search_pack(lcode, ccode, csolved, n, pitch, 3, leaf, child, solved, NULL));
+        CK(hipMemcpy(hrec, leaf, n * 20, hipMemcpyDeviceToHost));
+        for (int c = 0; c < n; ++c)
+            for (int p = 0; p < 20; ++p)                                                        /* solved cube: piece p in slot p, orientation 0 */
+                if (hrec[c * 20 + p] != (p < 8 ? 3 * p : 2 * (p - 8))) { fprintf(stderr, "leaf code cube %d slot %d: %d\n", c, p, hrec[c * 20 + p]); return 31; }
+        CK(hipMemcpy(hrec, solved, n * 12, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n * 12; ++i) if (hrec[i] != 0) return 32;
+        CK(hipMemcpy(hrec, child, n * 12 * 20, hipMemcpyDeviceToHost));
+        if (memcmp(hrec, hrec + 4 * 12 * 20, 12 * 20) != 0) return 33;                           /* every cube is the same cube */
+        if (rc_apply_moves_ex(st, st, act, n, pitch, pitch, 3, reward, done, NULL, RC_FMT_NONE, 0, NULL, RC_VARIANT_ADI_SEGS(2)) != RC_EINVAL) return 34;
+        if (rc_describe_dispatch(RC_OP_EXPAND, 3, 4096, 0, RC_OUT_FLAGS, RC_FMT_NONE, RC_VARIANT_STEP_POLICY(1), what, (int)sizeof what) != RC_EINVAL) return 35;
+        RC(rc_describe_dispatch(RC_OP_FAMILY_TO_DENSE, 3, 200, 30, 0, RC_FMT_F32, 0, what, (int)sizeof what));
+        if (!strstr(what, "family> depths=30")) { fprintf(stderr, "describe: %s\n", what); return 36; }
+        CK(hipHostFree(paths)); CK(hipFree(work)); CK(hipFree(ccode)); CK(hipFree(csolved)); CK(hipFree(lcode)); CK(hipFree(leaf)); CK(hipFree(child)); CK(hipFree(solved));
     }
     uint32_t status = 99;
     RC(rc_read_status(&status, NULL));

@@ -508,3 +508,63 @@ def test_graph_plan_notices_reallocated_parameters():
     assert torch.allclose(a["target_value"], b["target_value"], atol=1e-5) and torch.allclose(a["error"], b["error"], atol=1e-5)
     assert float((a["target_value"] - gp_before).abs().max()) > 0.1              # (and the values did change with the weights)
     assert next(iter(gp._graphs.values())) is not first                         # captured again
+
+
+def test_round5_entry_points_empty_and_error_paths(ops, L):
+    """n = 0 / depth 0 are no-ops, bad pointers / strides / formats are RC_EINVAL with a message, through the raw C ABI."""
+    lib, P = L.lib(), L.ptr
+    L.init(torch.device("cuda", torch.cuda.current_device()))
+    sp = L.stream_ptr(torch.device("cuda"))
+    z8 = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    zf = torch.zeros(1 << 14, dtype=torch.float32, device="cuda")
+    zd = torch.zeros(64, dtype=torch.float64, device="cuda")
+    zi = torch.zeros(1 << 12, dtype=torch.int32, device="cuda")
+    nf = L.family_layout(3)[0]
+    # rc_onehot_from_family_depths
+    assert lib.rc_onehot_from_family_depths(P(z8), 0, 256, 3, P(zf), L.FMT_F32, 0, 3, sp) == 0                # no walks
+    assert lib.rc_onehot_from_family_depths(P(z8), 8, 256, 3, P(zf), L.FMT_F32, 8, 0, sp) == 0                # no depths
+    for args in ((None, 8, 256, 3, P(zf), L.FMT_F32, 8, 1), (P(z8), 8, 256, 2, P(zf), L.FMT_F32, 8, 1), (P(z8), 8, 256, 3, P(zf), L.FMT_CODE, 8, 1),
+                 (P(z8), 8, 256, 3, None, L.FMT_F32, 8, 1), (P(z8), 8, 256, 3, P(zf), L.FMT_F32, 7, 1), (P(z8), 8, 100, 3, P(zf), L.FMT_F32, 8, 1),
+                 (P(z8), 8, 256, 3, P(zf), L.FMT_F32, 8, -1), (P(z8), 8, 256, 3, P(zf), L.FMT_F32, 8, 6000), (P(z8), -1, 256, 3, P(zf), L.FMT_F32, 8, 1)):
+        assert lib.rc_onehot_from_family_depths(*args, sp) == -1 and lib.rc_last_error(), args
+    assert nf * 256 <= z8.numel()
+    # rc_adi_targets_depths
+    assert lib.rc_adi_targets_depths(P(zf), 13 * 8, 8, P(z8), 256, P(zf), 13 * 8, P(zd), 0, 2, 3, P(zf), P(zi), P(zd), 2, sp) == 0
+    assert lib.rc_adi_targets_depths(P(zf), 13 * 8, 8, P(z8), 256, P(zf), 13 * 8, P(zd), 8, 0, 3, P(zf), P(zi), P(zd), 2, sp) == 0
+    ok = [P(zf), 13 * 8, 8, P(z8), 256, P(zf), 13 * 8, P(zd), 8, 2, 3, P(zf[4096:]), P(zi), P(zd[32:]), 2]
+    assert lib.rc_adi_targets_depths(*ok, sp) == 0
+    for i, bad in ((0, None), (3, None), (11, None), (12, None), (4, 4), (2, 4), (14, 1), (8, -1), (9, -1), (5, None), (7, None)):
+        args = list(ok)
+        args[i] = bad
+        assert lib.rc_adi_targets_depths(*args, sp) == -1 and lib.rc_last_error(), (i, bad)
+    args = list(ok); args[13] = None                                                      # no error output: parent / weight not needed
+    args[5] = None; args[7] = None
+    assert lib.rc_adi_targets_depths(*args, sp) == 0
+    args = list(ok); args[10] = 4
+    assert lib.rc_adi_targets_depths(*args, sp) == -1
+    # rc_scramble_from / rc_search_pack / rc_host_alias / rc_legacy_scramble_actions_ex
+    st = ops.alloc_states(16, 3, "cuda")
+    ops.fill_solved(st, 16, 3)
+    assert lib.rc_scramble_from(P(st), P(st), 0, 256, 3, 4, 0, 0, 0, None, None, 0, None, None, sp) == 0
+    assert lib.rc_scramble_from(None, P(st), 16, 256, 3, 4, 0, 0, 0, None, None, 0, None, None, sp) == -1
+    assert lib.rc_scramble_from(P(st), P(st), 16, 100, 3, 4, 0, 0, 0, None, None, 0, None, None, sp) == -1
+    assert lib.rc_scramble_from(P(st), P(st), 16, 256, 5, 4, 0, 0, 0, None, None, 0, None, None, sp) == -1
+    assert lib.rc_search_pack(P(z8), P(z8), P(z8), 0, 256, 3, P(z8), P(z8), P(z8), sp) == 0
+    for i in range(3):
+        args = [P(z8)] * 3 + [16, 256, 3] + [P(z8)] * 3
+        args[(0, 4, 7)[i]] = (None, 100, None)[i]
+        assert lib.rc_search_pack(*args, sp) == -1 and lib.rc_last_error()
+    assert lib.rc_search_pack(P(z8), P(z8), P(z8), 16, 256, 4, P(z8), P(z8), P(z8), sp) == -1
+    import ctypes
+    out = ctypes.c_void_p(0)
+    assert lib.rc_host_alias(None, ctypes.byref(out)) == -1 and lib.rc_host_alias(P(z8), None) == -1
+    assert lib.rc_host_alias(P(z8), ctypes.byref(out)) == -1                               # device memory is not host-mapped memory
+    seeds = torch.zeros(16, dtype=torch.int32, device="cuda")
+    assert lib.rc_legacy_scramble_actions_ex(P(seeds), None, 3, 3, 0, 3, P(z8), 256, sp, 0) == 0
+    assert lib.rc_legacy_scramble_actions_ex(P(seeds), None, 0, 0, 16, 3, P(z8), 256, sp, 2) == 0        # kmax 0: nothing to draw
+    assert lib.rc_legacy_scramble_actions_ex(P(seeds), None, 4, 3, 16, 3, P(z8), 256, sp, 0) == -1       # count_uniform > kmax
+    assert lib.rc_legacy_scramble_actions_ex(P(seeds), None, 3, 3, 16, 3, P(z8[1:]), 256, sp, 0) == -1   # misaligned output
+    assert lib.rc_legacy_scramble_actions_ex(P(seeds), None, 3, 3, 16, 4, P(z8), 256, sp, 0) == -1
+    assert lib.rc_legacy_scramble_actions_ex(None, None, 3, 3, 16, 3, P(z8), 256, sp, 0) == -1
+    torch.cuda.synchronize()
+    assert L.read_status() == 0

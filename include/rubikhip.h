@@ -188,8 +188,8 @@ int rc_legacy_scramble_actions(const uint32_t *seeds, const int32_t *counts, int
                                void *stream);
 /* Same with the generator form chosen by the caller (RC_VARIANT_LEGACY_*; 0 = rc_legacy_scramble_actions).  Two forms produce the
  * same bytes: the LDS form keeps MT19937's 624-word state per env in LDS (any count; the twist is done lazily, 64 words at a time);
- * the STREAMING form computes outputs 0..226 of the first generation from two init_genrand chain iterators in registers (no state at
- * all) and is followed by a fix-up launch of the LDS form for the waves in which a lane needed more -- the default up to kmax = 128. */
+ * the STREAMING form computes outputs 0..622 of the first generation from a few init_genrand chain iterators in registers (no state at
+ * all) and is followed by a fix-up launch of the LDS form for the waves in which a lane needed more -- the default up to kmax = 400. */
 int rc_legacy_scramble_actions_ex(const uint32_t *seeds, const int32_t *counts, int count_uniform, int kmax,
                                   int64_t n_envs, int cube_size, uint8_t *actions_out, int64_t pitch,
                                   void *stream, int variant);
@@ -352,7 +352,7 @@ const char *rc_last_error(void);
                                                          4 = by one load of wave 0 + LDS */
 /* rc_legacy_scramble_actions_ex (not decimal: mode + 16 * limit) */
 #define RC_VARIANT_LEGACY_LDS 1                       /* the LDS form alone */
-#define RC_VARIANT_LEGACY_STREAM(limit) (2 + 16 * (limit)) /* the streaming form with `limit` outputs per lane (1..227; 0 = 227) + fix-up */
+#define RC_VARIANT_LEGACY_STREAM(limit) (2 + 16 * (limit)) /* the streaming form with `limit` outputs per lane (1..623; 0 = 623) + fix-up */
 
 #ifdef __cplusplus
 }

@@ -871,11 +871,16 @@ __global__ void __launch_bounds__(kWave) k_legacy_actions(const uint32_t *seeds,
     }
 }
 
-// The common case -- reset(seed, k) with a few dozen moves -- needs no state at all.  Outputs 0..226 of the first generation are
-//   temper(x[k + 397] ^ twist(x[k], x[k + 1]))     with x = the init_genrand chain of the seed,
-// so two chain iterators (one at k, one 397 words ahead) produce them in registers: no LDS, full occupancy, ~25 VALU instructions per
-// output after a 397-step prelude.  A lane that still wants draws after `limit` (<= 227) outputs leaves kLegacyRedo in row 0 and the
-// wave is redone by the LDS kernel above (launched right behind this one in fixup mode): exact for every seed and count.
+// The common case -- reset(seed, k) with a few dozen moves -- needs no state at all.  With x = the init_genrand chain of the seed and
+// T(a, b) = genrand's twist term of (a, b), the first generation's words are
+//   new[k] = x[k + 397] ^ T(x[k], x[k + 1])                                 k <  227
+//   new[k] = new[k - 227] ^ T(x[k], x[k + 1])                               227 <= k < 623   (new[k - 227] itself by one of these two lines)
+// so a few chain iterators (at k, k - 227, k - 454 and 397 / 170 words ahead) produce outputs 0..622 in registers: no LDS, full
+// occupancy, 25-45 VALU instructions per output after a 397-step prelude.  (Word 623 needs new[0] as its neighbour and a second
+// generation the whole twisted state: those stay with the LDS kernel.)  A lane that still wants draws after `limit` (<= 623) outputs
+// leaves kLegacyRedo in row 0 and its wave is redone by the LDS kernel above (launched right behind this one in fixup mode): exact for
+// every seed and count.
+constexpr int kMtStreamMax = kMtN - 1;                          // outputs 0..622
 template <int A_>
 __global__ void __launch_bounds__(256) k_legacy_actions_stream(const uint32_t *seeds, const int32_t *counts, int count_uniform, int kmax,
                                                                int64_t n, uint8_t *actions_out, int64_t pitch, int limit) {
@@ -883,19 +888,52 @@ __global__ void __launch_bounds__(256) k_legacy_actions_stream(const uint32_t *s
     const bool live = env < n;
     int want = live ? (counts ? counts[env] : count_uniform) : 0;
     want = want < 0 ? 0 : want > kmax ? kmax : want;
-    uint32_t xa = live ? seeds[env] : 0u, xb = xa;
-    for (uint32_t i = 1; i <= (uint32_t)kMtM; ++i) xb = mt_next_seed(xb, i);        // xb = x[397]
+    const uint32_t x0 = live ? seeds[env] : 0u;
+    uint32_t x397 = x0;
+    for (uint32_t i = 1; i <= (uint32_t)kMtM; ++i) x397 = mt_next_seed(x397, i);
     constexpr uint32_t rng = A_ - 1;
     constexpr uint32_t mask = rng | rng >> 1 | rng >> 2 | rng >> 3;
+    constexpr int kP1 = kMtN - kMtM, kP2 = 2 * kP1;             // 227, 454: where the recursion gains a level
     int got = 0;
-    for (int k = 0; k < limit && __any(got < want); ++k) {
-        const uint32_t xa1 = mt_next_seed(xa, (uint32_t)k + 1u);
-        const uint32_t v = mt_temper(mt_twist(xa, xa1, xb)) & mask;
-        xa = xa1;
-        xb = mt_next_seed(xb, (uint32_t)(k + kMtM) + 1u);                            // (the word past x[623] is never used: limit <= 227)
-        if (got < want && v <= rng) {
+    auto emit = [&](uint32_t word) {
+        const uint32_t v = mt_temper(word) & mask;
+        if (got < want && v <= rng) {                          // masked rejection (numpy _bounded_integers, legacy path)
             actions_out[(int64_t)got * pitch + env] = (uint8_t)v;
             ++got;
+        }
+    };
+    uint32_t xa = x0;                                          // x[k]: runs through all three phases
+    int k = 0;
+    {
+        uint32_t xb = x397;                                    // x[k + 397]
+        for (; k < limit && k < kP1 && __any(got < want); ++k) {
+            const uint32_t xa1 = mt_next_seed(xa, (uint32_t)k + 1u);
+            emit(mt_twist(xa, xa1, xb));
+            xa = xa1;
+            xb = mt_next_seed(xb, (uint32_t)(k + kMtM) + 1u);  // (the word past x[623] is computed once and never used)
+        }
+    }
+    const uint32_t x227 = xa;                                  // (meaningful when phase 1 ran to its end, which phases 2 and 3 require)
+    if (k == kP1) {
+        uint32_t xc = x0, xd = x397;                           // x[k - 227], x[k + 170]
+        for (; k < limit && k < kP2 && __any(got < want); ++k) {
+            const uint32_t xa1 = mt_next_seed(xa, (uint32_t)k + 1u), xc1 = mt_next_seed(xc, (uint32_t)(k - kP1) + 1u);
+            emit(mt_twist(xa, xa1, mt_twist(xc, xc1, xd)));    // new[k - 227] = x[k + 170] ^ T(x[k - 227], x[k - 226])
+            xa = xa1;
+            xc = xc1;
+            xd = mt_next_seed(xd, (uint32_t)(k + 170) + 1u);
+        }
+    }
+    if (k == kP2) {
+        uint32_t xe = x227, xf = x0, xg = x397;                // x[k - 227], x[k - 454], x[k - 57]
+        for (; k < limit && k < kMtStreamMax && __any(got < want); ++k) {
+            const uint32_t xa1 = mt_next_seed(xa, (uint32_t)k + 1u), xe1 = mt_next_seed(xe, (uint32_t)(k - kP1) + 1u), xf1 = mt_next_seed(xf, (uint32_t)(k - kP2) + 1u);
+            const uint32_t n0 = mt_twist(xf, xf1, xg);         // new[k - 454] = x[k - 57] ^ T(x[k - 454], x[k - 453])
+            emit(mt_twist(xa, xa1, mt_twist(xe, xe1, n0)));    // new[k - 227] = new[k - 454] ^ T(x[k - 227], x[k - 226])
+            xa = xa1;
+            xe = xe1;
+            xf = xf1;
+            xg = mt_next_seed(xg, (uint32_t)(k - 57) + 1u);
         }
     }
     if (!live) return;
@@ -1756,11 +1794,11 @@ int rc_search_pack(const uint8_t *leaf_code, const uint8_t *child_code, const ui
 }
 
 // Which generator form runs (`variant` of rc_legacy_scramble_actions_ex; include/rubikhip.h RC_VARIANT_LEGACY_*): 0 = by kmax,
-// 1 = the LDS kernel alone, 2 + 16 * limit = the streaming kernel with `limit` outputs per lane (1..227; 0 = 227) + the fixup launch.
+// 1 = the LDS kernel alone, 2 + 16 * limit = the streaming kernel with `limit` outputs per lane (1..623; 0 = 623) + the fixup launch.
 // Default rule: a draw is accepted with probability 3/4, so k draws consume k / 0.75 outputs on average with a standard deviation of
-// sqrt(k) * 0.67: up to kmax = 128 (171 +- 7.5) the 227 streamed outputs are never short in practice, and when they are the fixup
+// sqrt(k) * 0.67: up to kmax = 400 (533 +- 13) the 623 streamed outputs are never short in practice, and when they are the fixup
 // launch redoes that wave -- the rule only decides which kernel does the bulk.
-constexpr int kLegacyStreamMax = 128;
+constexpr int kLegacyStreamMax = 400;
 int rc_legacy_scramble_actions_ex(const uint32_t *seeds, const int32_t *counts, int count_uniform, int kmax, int64_t n, int cube_size,
                                    uint8_t *actions_out, int64_t pitch, void *stream, int variant) {
     RC_NEED_INIT();
@@ -1769,14 +1807,14 @@ int rc_legacy_scramble_actions_ex(const uint32_t *seeds, const int32_t *counts, 
     if (!counts && (count_uniform < 0 || count_uniform > kmax)) return fail(RC_EINVAL, "rc_legacy_scramble_actions: count_uniform must be in 0..kmax%s");
     if (cube_size != 2 && cube_size != 3) return fail(RC_EINVAL, "cube_size must be 2 or 3%s");
     const int mode = variant & 15, lim = variant >> 4;
-    if (variant < 0 || mode > 2 || lim > 227 || (mode != 2 && lim != 0)) return fail(RC_EINVAL, "rc_legacy_scramble_actions: unknown variant%s");
+    if (variant < 0 || mode > 2 || lim > kMtStreamMax || (mode != 2 && lim != 0)) return fail(RC_EINVAL, "rc_legacy_scramble_actions: unknown variant%s");
     if (n == 0 || kmax == 0) return RC_OK;
     const int64_t waves = (n + kWave - 1) / kWave;
     RC_GRID(waves);
     const bool streamed = mode == 2 || (mode == 0 && kmax <= kLegacyStreamMax);
     if (streamed) {
         const dim3 g((unsigned)((n + 255) / 256)), b(256);
-        const int limit = lim ? lim : 227;
+        const int limit = lim ? lim : kMtStreamMax;
         if (cube_size == 3) hipLaunchKernelGGL((k_legacy_actions_stream<12>), g, b, 0, S(stream), seeds, counts, count_uniform, kmax, n, actions_out, pitch, limit);
         else hipLaunchKernelGGL((k_legacy_actions_stream<6>), g, b, 0, S(stream), seeds, counts, count_uniform, kmax, n, actions_out, pitch, limit);
         RC_HIP(hipGetLastError());

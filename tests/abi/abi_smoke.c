@@ -133,6 +133,7 @@ int main(void) {
             for (int d = 0; d < 5; ++d) if (hd[d * 256] != want[d]) { fprintf(stderr, "legacy draw %d form %d: %d\n", d, f, hd[d * 256]); return 26; }
         }
         if (rc_legacy_scramble_actions_ex(seeds, NULL, 5, 5, 1, 3, draws, 256, NULL, 3) != RC_EINVAL) return 27;
+        if (rc_legacy_scramble_actions_ex(seeds, NULL, 5, 5, 1, 3, draws, 256, NULL, RC_VARIANT_LEGACY_STREAM(624)) != RC_EINVAL) return 27;
         CK(hipFree(seeds)); CK(hipFree(draws));
     }
     /* (2) rc_scramble_from replays R U R' U' that it READS from pinned host memory (rc_host_alias) out of untouched solved cubes;

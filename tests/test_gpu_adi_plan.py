@@ -182,18 +182,19 @@ def _numpy_legacy(seeds, ks, A):
 @pytest.mark.parametrize("cs", [3, 2])
 def test_legacy_generator_forms_agree_with_numpy(ops, L, cs):
     """reset(seed, k)'s draws (cube_env.py:62-65) from both device forms of numpy's legacy generator: the LDS form (lazy twist), the
-    streaming form at its default limit, and the streaming form with a limit so low that most waves overflow and are redone by the
-    fix-up launch -- every byte equal to numpy's, pad rows = the no-op."""
+    streaming form at its default limit, at the boundaries of its three phases (227 / 454 outputs) and with a limit so low that most
+    waves overflow and are redone by the fix-up launch -- every byte equal to numpy's, pad rows = the no-op."""
     A = 12 if cs == 3 else 6
     rng = np.random.default_rng(cs)
     n = 1500
     seeds = rng.integers(0, 2 ** 32, n, dtype=np.uint64)
     seeds[:4] = (0, 1, 2 ** 32 - 1, 10)
-    for ks, label in ((np.full(n, 30), "k=30"), (rng.integers(0, 61, n), "mixed 0..60"), (np.r_[rng.integers(1, 40, n - 3), [170, 171, 200]], "up to 200")):
+    for ks, label in ((np.full(n, 30), "k=30"), (rng.integers(0, 61, n), "mixed 0..60"), (np.r_[rng.integers(1, 40, n - 3), [170, 171, 200]], "up to 200"),
+                      (np.r_[rng.integers(150, 420, n - 4), [455, 460, 470, 340]], "up to 470: all three phases of the streaming form, overflow into the fix-up")):
         want = _numpy_legacy(seeds, ks, A)
         kmax = int(ks.max())
         uniform = int(ks[0]) if (ks == ks[0]).all() else None
-        for variant in (0, 1, 2, 2 + 16 * 40, 2 + 16 * 7, 2 + 16 * 227):
+        for variant in (0, 1, 2, 2 + 16 * 40, 2 + 16 * 7, 2 + 16 * 227, 2 + 16 * 228, 2 + 16 * 454, 2 + 16 * 455, 2 + 16 * 623):
             buf, kk = ops.legacy_scramble_actions(torch.from_numpy(seeds.astype(np.int64)), cs, uniform if uniform is not None else ks.tolist(), device="cuda", variant=variant)
             got = buf.cpu().numpy()
             assert kk == kmax
@@ -208,7 +209,7 @@ def test_legacy_generator_forms_agree_with_numpy(ops, L, cs):
         got = buf.cpu().numpy()
         for i in range(5):
             assert (got[:ks[i], i] == want[i]).all() and (got[ks[i]:, i] == A).all(), (variant, i)
-    for bad in (3, 2 + 16 * 228, -1, 1 + 16):
+    for bad in (3, 2 + 16 * 624, -1, 1 + 16):
         with pytest.raises(L.RubikHipError):
             ops.legacy_scramble_actions(torch.arange(4), cs, 3, device="cuda", variant=bad)
 
@@ -473,11 +474,11 @@ def test_round5_entry_points_random_shapes(ops, L, oracle):
         A = 12 if cs == 3 else 6
         n = int(rng.choice([1, 63, 64, 65, 255, 257, 1000, 4099]))
         seeds = rng.integers(0, 2 ** 32, n, dtype=np.uint64)
-        kmax = int(rng.choice([1, 2, 30, 64, 129, 260]))
+        kmax = int(rng.choice([1, 2, 30, 64, 129, 260, 401, 480]))
         ks = rng.integers(0, kmax + 1, n)
         ks[0] = kmax
         want = _numpy_legacy(seeds, ks, A)
-        variant = [0, 1, 2, 2 + 16 * int(rng.integers(1, 228))][case % 4]
+        variant = [0, 1, 2, 2 + 16 * int(rng.integers(1, 624))][case % 4]
         buf, kk = ops.legacy_scramble_actions(torch.from_numpy(seeds.astype(np.int64)), cs, ks.tolist(), device="cuda", variant=variant)
         got = buf.cpu().numpy()
         for i in range(n):

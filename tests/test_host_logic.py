@@ -320,7 +320,7 @@ def test_variant_macros_round_trip_through_describe_dispatch():
     assert "parts=6 " in L.describe(L.OP_EXPAND, 2, n, outputs=L.OUT_STATES, variant=M["RC_VARIANT_EXPAND_PARTS"](6))
     with pytest.raises(L.RubikHipError, match="variant"):
         L.describe(L.OP_EXPAND, 2, n, outputs=L.OUT_STATES, variant=M["RC_VARIANT_EXPAND_PARTS"](7))
-    assert M["RC_VARIANT_LEGACY_LDS"] == 1 and M["RC_VARIANT_LEGACY_STREAM"](0) == 2 and M["RC_VARIANT_LEGACY_STREAM"](40) == 642
+    assert M["RC_VARIANT_LEGACY_LDS"] == 1 and M["RC_VARIANT_LEGACY_STREAM"](0) == 2 and M["RC_VARIANT_LEGACY_STREAM"](40) == 642 and M["RC_VARIANT_LEGACY_STREAM"](623) == 9970
 
 
 def test_cube_env_has_no_backend_parameter():

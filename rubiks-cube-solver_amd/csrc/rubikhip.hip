@@ -13,8 +13,8 @@
 //                     shape of a fill kernel: 0.85-0.94 of the HBM peak wherever the buffer lives); also expands the ADI
 //                     family record to its 13 dense blocks; second launch of rc_apply_moves_ws / rc_encode_ws
 //   k_scramble        reset()'s scramble loop, in place or out of untouched start states (the lockstep search's replay)    cube_env.py:65-67
-//   k_legacy_actions_stream / k_legacy_actions   numpy's legacy MT19937 draws of reset(seed, k), one env per lane: the first generation (622 outputs)
-//                     from two init_genrand chain iterators in registers, the general form with the state in LDS    cube_env.py:62-65
+//   k_legacy_actions_stream / k_legacy_actions   numpy's legacy MT19937 draws of reset(seed, k), one env per lane: the first generation (outputs 0..622)
+//                     from a few init_genrand chain iterators in registers, the general form with the state in LDS    cube_env.py:62-65
 //   k_expand          12 children of every cube         cube_env.py:212-236, mcts.py:96-101
 //   k_adi             ADI walks + expansion, persistent over depth, per-walk xoroshiro128+; outputs: stickers, picked codes,
 //                     or the 51-row FAMILY record (the shared look-ups themselves)    cube_env.py:177-194,212-236

@@ -366,6 +366,29 @@ def pipeline_configs(torch, ops, _lib, dev):
             ap[key]["frac_of_fp32_mfma_peak"] = round(tf / 157.3, 3)
         ap["bound"] = ("the caller's value net: 1.64 MFLOP per state in float32 against the 157.3 TFLOP/s fp32 MFMA peak (MI355X_MICROARCH.md); the env kernels are "
                        "under 5 % of a call (profiles/r05_adi_pipeline.json)")
+        # the drop-in call itself (cube_env.py:177-194 as train.py:152-155 issues it): host draws with numpy's global generator, the plan,
+        # the replay sink, and the env left on the last walk's final state
+        import numpy as np
+        import rubiks_cube_solver_amd as rc
+        env = rc.make_env(dev, CUBE)
+        sink = rc.TensorReplayBuffer(500_000, 100_000, CUBE)
+        for graph in (False, True):
+            env.adi_graph = graph
+            for _ in range(3):
+                env.get_random_samples(sink, model, 30, 200, 1.0)
+            torch.cuda.synchronize()
+            times = []
+            for _ in range(7):
+                t0 = time.perf_counter()
+                env.get_random_samples(sink, model, 30, 200, 1.0)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+            ap["CubeEnv.get_random_samples_200x30" + ("_hipgraph" if graph else "")] = {
+                "seconds": round(sorted(times)[3], 5), "samples_per_s": round(6000 / sorted(times)[3], 1),
+                "what": "env.get_random_samples(TensorReplayBuffer, model, 30, 200, 1.0): 200 np.random.randint draws on the host + upload + AdiPlan.run + append_batch + "
+                        "the env's own state update; the reference's call takes 15 s on one CPU core (393 samples/s)"}
+        env.close()
+        del sink
         ap["2x2x2_20000x14"] = adi_run(sizes=((20_000, 14),), reps=3, dev=dev, cube_size=2)["20000x14"]      # the shipped checkpoint's layer sizes (147-512-128-64)
         ap["note"] = ("median wall time of one adi_samples call incl. its final synchronisation; net = random-init DeepCube [1024,256,128] in float32 (the reference's "
                       "config); the reference does 393 samples/s on one CPU core (SURVEY.md section 6)")

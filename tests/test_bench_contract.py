@@ -65,6 +65,7 @@ def test_bench_json_line():
     ap = d["configs"]["adi_pipeline"]
     for size in ("200x30", "20000x30", "100000x30", "200x30_hipgraph", "2x2x2_20000x14"):
         assert ap[size]["seconds"] > 0 and ap[size]["samples_per_s"] > 0, ap
+    assert ap["CubeEnv.get_random_samples_200x30"]["seconds"] < 6e-3 and ap["CubeEnv.get_random_samples_200x30_hipgraph"]["seconds"] < 6e-3, ap
     assert ap["200x30"]["seconds"] < 3e-3 and ap["20000x30"]["samples_per_s"] > 4e6 and ap["100000x30"]["samples_per_s"] > 4e6, ap   # the round-4 review's bars
     ro = d["configs"]["rollout"]
     assert all(ro[k]["us_per_timestep"] > 0 for k in ("n300_eager", "n300_hipgraph", "n65536_eager", "n65536_hipgraph")), ro

@@ -217,14 +217,15 @@ def test_bench_many_ranks_rehearsal(oracle):
     assert len(shas) == ranks
 
 
-def test_bench_eight_ranks_dry_run():
+@pytest.mark.parametrize("ranks", [2, 4, 8])
+def test_bench_eight_ranks_dry_run(ranks):
     """The N = 8 line's plumbing without a GPU (RC_BENCH_DRY=1: no kernel, numbers mean nothing): the driver's launcher shape
     (`torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8`), a process group, eight contiguous stream ids, barrier,
     all_gather, MAX over ranks, ONE JSON line from rank 0 with eight `per_gpu` entries and total_cubes = 8 x 2^20 -- so that the first
     real 8-GPU run cannot fail on anything but the kernels (which the one-GPU tests cover).  Pattern: train.py:85-92."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", RC_BENCH_DRY="1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
-           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "1", "--backend", "gloo",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "5", "--warmup", "1", "--backend", "gloo",
            "--cubes-per-gpu", str(1 << 20)]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -235,12 +236,14 @@ def test_bench_eight_ranks_dry_run():
               "config", "roofline", "per_gpu"):
         assert k in d, k
     assert d["dry_run"] is True and "NO kernel ran" in d["data"] and "cpu_baseline" not in d and "configs" not in d
-    assert d["n_gpus"] == 8 and d["steps"] == 5 and d["scaling"] == "weak" and d["unit"] == "steps/s" and d["dtype"] == "u8"
-    assert d["config"]["cubes_per_gpu"] == 1 << 20 and d["config"]["total_cubes"] == 8 << 20 and "configs[3]" in d["config"]["workload"]
-    assert d["config"]["process_group"] == "gloo" and d["config"]["parallelism"].startswith("8 independent ranks")
-    assert [r["rank"] for r in d["per_gpu"]] == list(range(8)) and [r["stream_id"] for r in d["per_gpu"]] == list(range(8))
+    assert d["n_gpus"] == ranks and d["steps"] == 5 and d["scaling"] == "weak" and d["unit"] == "steps/s" and d["dtype"] == "u8"
+    assert d["config"]["cubes_per_gpu"] == 1 << 20 and d["config"]["total_cubes"] == ranks << 20 and "configs[3]" in d["config"]["workload"]
+    assert d["config"]["process_group"] == "gloo" and d["config"]["parallelism"].startswith(f"{ranks} independent ranks")
+    assert [r["rank"] for r in d["per_gpu"]] == list(range(ranks)) and [r["stream_id"] for r in d["per_gpu"]] == list(range(ranks))
     assert d["roofline"]["kernel"].startswith("k_step<Cube3,V=2,move,store,POL=0>")         # 1M cubes per GPU: the resident policy
     assert d["roofline"]["aggregate_GBps"] > 0 and "aggregate_frac_of_n_x_peak" in d["roofline"]
+    if ranks != 8:
+        return
     # a dry run refuses the RCCL backend (it would touch the GPUs)
     env1 = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--backend", "nccl"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env1)

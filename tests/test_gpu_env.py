@@ -303,6 +303,7 @@ def test_solve_percentage_shape(mod):
     net = TinyNet([7, 21], 6, seed=1).cuda()
     pct = solve_percentage(net, 2, 4, 25, 12, device="cuda")
     assert len(pct) == 4 and all(0.0 <= p <= 100.0 for p in pct)
+    assert solve_percentage(net, 2, 4, 25, 12, device="cuda", graph=True) == pct       # one time step replayed as a hipGraph: the same rollouts
 
 
 def test_mcts_class_and_batched_mcts(mod, oracle):

@@ -11,8 +11,16 @@ HBM-resident state buffers.  C defaults to 2^22 (the metric's batch: working set
 Cache); --cubes-per-gpu 1048576 is BASELINE config 4's shape (1M cubes per GPU x N GPUs).
 Inputs are resident in HBM before the timed region.  value = cubes * K * N / max-over-ranks time of the K timed steps.
 Every rank owns its own batch and RNG stream (stream_id = rank); there is no collective on the
-env path ("scaling": "weak").  One JSON line is printed by rank 0; in the distributed branch it carries `per_gpu` (each rank's
-stream_id, rate and a sha256 of its first 65536 scrambled cubes, which the tests compare with the oracle's (seed, rank) stream).
+env path ("scaling": "weak").
+
+OUTPUT.  stdout carries exactly ONE line, printed last by rank 0: the COMPACT record (compact_record(): the contract's keys,
+`roofline`, `cpu_baseline`, ten scalar `extras`, under 4 KB, no string over 120 characters -- round 5's 23.5 KB line came back from
+the driver unparsed).  The FULL record (every per-config roofline record, the notes, per-rank details) is written to --full-out
+(default bench_full.json next to this file; the builder's copies live under profiles/).  In the distributed branch the full record's
+`per_gpu` carries each rank's stream_id, device index, PCI bus id, rate and a sha256 of its first 65536 scrambled cubes (the tests
+compare it with the oracle's (seed, rank) stream); the compact line carries the short form and `config.distinct_devices`.  One rank
+per GPU: a launch with more ranks than visible devices is REFUSED unless --share-gpu marks it as a rehearsal.  At N > 1 the other
+configs are skipped unless --configs is given, so rank 0 exits with its peers.
 The distributed branch (process group, barrier, all_gather, MAX over ranks) runs for N > 1, under a launcher at N = 1
 (torch.distributed.run --nproc-per-node 1) and with --force-dist, so the code the 2/4/8-GPU runs execute can be exercised on one GPU.
 
@@ -27,8 +35,8 @@ whose 1.8 GB ping-pong defeats the Infinity Cache (the HBM-only point: roofline.
 bf16 / u8), code -> dense (f32 / bf16 / f16 / u8), 2x2x2 step / expansion / dense, config 3 (ADI 100k walks x 30, 715 B per (walk,
 depth)) and its code / family forms, the family -> dense-block launch of the ADI pipeline, the 1M-parent expansion.  Then the loops
 the reference actually runs, end to end on the host clock: `adi_pipeline` (get_random_samples batched: 200 x 30 = the reference's
-own size, 20k x 30, 100k x 30, and the hipGraph replay), `config5_mcts_4096_leaves` (config 5: us per MCTS step eager / hipGraph /
-two streams, the lockstep search's device step + transfers and whole simulations split select / device / update), `rollout`
+own size, 20k x 30, 100k x 30, and the hipGraph replay), `config5_mcts_4096_leaves` (config 5: us per MCTS step eager / hipGraph,
+the lockstep search's device step + transfers and whole simulations split select / device / update), `rollout`
 (greedy validation rollouts), `reset_seeds_1M_k30` (reset(seed, 30) for 1M envs, numpy's legacy generator on the device) and the
 batch-1 facade latency.  --no-configs skips them.  RC_BENCH_DRY=1 (with --backend gloo) runs the N-rank plumbing without a GPU.
 """
@@ -98,7 +106,7 @@ def numpy_env_all_cores(seconds=1.5, procs=None):
     return float(sum(rates)), procs
 
 
-def cpu_baseline(budget_s=8.0):
+def cpu_baseline(budget_s=5.0):
     """The C oracle (kind "port") timed on this box's host cores, same workload shape, bounded sample."""
     import numpy as np
     from oracle.oracle_np import Oracle, OracleCubeEnv
@@ -135,6 +143,7 @@ def cpu_baseline(budget_s=8.0):
         "affinity_cores": affinity, "cgroup_cpu_quota": quota, "cpu_share_used": share, "host_logical_cores": os.cpu_count(),
         "sample": f"C oracle (oracle/rc_oracle.c, OpenMP, {res['all']['threads']} threads = this job's CPU share) step = move+solved flag "
                   f"on 2^20 cubes x {res['all']['iters']} passes ({res['all']['seconds']:.1f} s)",
+        "sample_short": f"C oracle, OpenMP x{res['all']['threads']}: move + solved flag, 2^20 cubes x {res['all']['iters']} passes ({res['all']['seconds']:.1f} s)",
         "single_core_steps_per_s": res["single"]["steps_per_s"],
         "numpy_env_1core_steps_per_s": np_rate,
         "numpy_env_allcores_steps_per_s": np_all, "numpy_env_processes": np_procs,
@@ -465,6 +474,12 @@ def main():
     ap.add_argument("--backend", default="nccl", help="process-group backend of the distributed branch (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the distributed branch (process group, barrier, all_gather, MAX over ranks) even at world size 1")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: let ranks fold onto the same GPU (local_rank %% device_count) when world > device_count; without it "
+                         "such a launch is refused")
+    ap.add_argument("--configs", action="store_true", help="N > 1: run the other BASELINE configs on rank 0 too (default there: skipped, rank 0 exits with the others)")
+    ap.add_argument("--full-out", default=os.path.join(ROOT, "bench_full.json"),
+                    help="where the FULL record (per-config records, notes, per-rank details) is written; stdout carries only the compact line")
     ap.add_argument("--batches", type=int, default=0, help="event-timed batches of --steps launches after the timed region (0 = max(7, 140 / steps))")
     args = ap.parse_args()
     if args.cubes_per_gpu < 1:
@@ -495,9 +510,21 @@ def main():
     dry = os.environ.get("RC_BENCH_DRY") == "1"
     if dry and args.backend != "gloo":
         sys.exit("RC_BENCH_DRY=1 needs --backend gloo (no GPU is touched)")
-    dev_index = local_rank % max(1, torch.cuda.device_count())      # one rank per GPU (rehearsals may share one)
+    # one rank per GPU: rank r asks for device LOCAL_RANK and nothing else.  A launch with more ranks than devices is refused (it
+    # would silently fold ranks onto one GPU and report an "8-GPU" line from fewer) unless --share-gpu says it is a rehearsal.
+    n_devices = torch.cuda.device_count()
+    dev_index = local_rank
     if not dry:
+        if n_devices < 1:
+            sys.exit("bench.py needs a GPU (RC_BENCH_DRY=1 --backend gloo rehearses the plumbing without one)")
+        if local_rank >= n_devices:
+            if not args.share_gpu:
+                sys.exit(f"rank {rank}: LOCAL_RANK {local_rank} >= {n_devices} visible device(s); one rank per GPU is the contract "
+                         "(--share-gpu folds ranks onto the same GPU for a rehearsal)")
+            dev_index = local_rank % n_devices
         torch.cuda.set_device(dev_index)
+    if world > 1 and not args.configs:
+        args.no_configs = True                                        # rank 0 leaves with the others; N = 1 carries the per-config records
     dev = torch.device("cuda", dev_index)
     if use_dist:
         # reporting only (barrier + MAX of elapsed time): the env path itself has no collective
@@ -515,7 +542,7 @@ def main():
     stream_id = rcdist.rng_stream(rank)                              # rank-distinct RNG stream, no exchange between ranks
     k = min(n, SAMPLE_CUBES)
     if dry:
-        device_name, sample_sha = "dry run (no GPU)", "dry-run"
+        device_name, sample_sha, pci = "dry run (no GPU)", "dry-run", None
 
         def step():
             pass
@@ -536,6 +563,8 @@ def main():
         launch_us = launch_min = launch_max = elapsed / args.steps * 1e6
     else:
         device_name = torch.cuda.get_device_name(dev_index)
+        props = torch.cuda.get_device_properties(dev_index)
+        pci = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}"      # which physical card this rank ran on
         a = ops.alloc_states(n, CUBE, dev)
         b = torch.empty_like(a)
         ops.fill_solved(a, n, CUBE)
@@ -588,8 +617,11 @@ def main():
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)                                     # reporting only: per-GPU figures beside the aggregate (config 4)
         shas = [None] * world
-        dist.all_gather_object(shas, {"stream_id": stream_id, "sha": sample_sha, "device": device_name})
-        per_rank = [{"rank": r, "stream_id": shas[r]["stream_id"], "ms_per_step": float(x[0]) / args.steps * 1e3,
+        dist.all_gather_object(shas, {"stream_id": stream_id, "sha": sample_sha, "device": device_name, "device_index": dev_index,
+                                      "requested_device_index": local_rank, "pci_bus_id": pci, "pid": os.getpid()})
+        per_rank = [{"rank": r, "stream_id": shas[r]["stream_id"], "device_index": shas[r]["device_index"],
+                     "requested_device_index": shas[r]["requested_device_index"], "pci_bus_id": shas[r]["pci_bus_id"], "device": shas[r]["device"],
+                     "ms_per_step": float(x[0]) / args.steps * 1e3,
                      "launch_us": float(x[2]), "launch_us_timed_region": float(x[1]) / args.steps * 1e3, "steps_per_s": n * args.steps / float(x[0]),
                      "GBps": BYTES_PER_STEP * n / (float(x[2]) * 1e-6) / 1e9,
                      "initial_state_sha256_first_cubes": shas[r]["sha"], "sha_cubes": k}
@@ -686,13 +718,97 @@ def main():
         out["roofline"]["aggregate_GBps"] = sum(r["GBps"] for r in per_rank)
         out["roofline"]["aggregate_frac_of_n_x_peak"] = out["roofline"]["aggregate_GBps"] / (HBM_PEAK_GBPS * world)
         out["config"]["process_group"] = args.backend
+        # which card every rank ran on: distinct_devices < n_gpus means ranks shared a GPU (a --share-gpu rehearsal), never silently
+        cards = {(r["pci_bus_id"] or f"requested:{r['requested_device_index']}") for r in per_rank}
+        out["config"]["distinct_devices"] = len(cards)
+        out["config"]["shared_gpu_rehearsal"] = bool(args.share_gpu and len(cards) < world)
+    else:
+        out["config"]["distinct_devices"] = 1
+        out["per_gpu"] = [{"rank": 0, "stream_id": stream_id, "device_index": dev_index, "requested_device_index": local_rank, "pci_bus_id": pci,
+                           "device": device_name}]
     if dry:
         out["dry_run"] = True
     if not args.no_cpu and world == 1 and not dry:
         out["cpu_baseline"] = cpu_baseline()
     if configs:
         out["configs"] = configs
-    print(json.dumps(out))
+    full_path = None
+    if args.full_out:
+        try:
+            with open(args.full_out, "w") as f:
+                json.dump(out, f)
+                f.write("\n")
+            full_path = os.path.relpath(args.full_out, ROOT) if os.path.abspath(args.full_out).startswith(ROOT + os.sep) else args.full_out
+            print(f"bench.py: full record ({os.path.getsize(args.full_out)} bytes) -> {args.full_out}", file=sys.stderr)
+        except OSError as e:                                         # a read-only tree: the compact line is still the record
+            print(f"bench.py: could not write the full record: {e}", file=sys.stderr)
+    line = json.dumps(compact_record(out, full_path), allow_nan=False, separators=(",", ":"))
+    assert len(line) < COMPACT_LIMIT, len(line)
+    print(line, flush=True)
+
+
+COMPACT_LIMIT = 4096      # the driver parses the LAST stdout line and keeps 8 KB of tail: round 5's 23.5 KB line came back unparsed
+
+
+def compact_record(full, full_path=None):
+    """The FINAL stdout line: the contract's keys, `roofline`, `cpu_baseline` and ten scalar extras -- no notes, no per-config table,
+    every string under 120 characters, the whole line under COMPACT_LIMIT bytes.  Everything else lives in the full record
+    (--full-out, default bench_full.json next to this file; the builder's copies are under profiles/)."""
+    def cut(v, n=118):
+        return v if not isinstance(v, str) or len(v) <= n else v[:n - 1] + "~"
+
+    def pick(d, keys):
+        return {k: cut(d[k]) for k in keys if k in d}
+
+    def sig(v, digits=6):
+        return float(f"{v:.{digits}g}") if isinstance(v, float) else v
+
+    out = pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    n, world = full["config"]["cubes_per_gpu"], full["n_gpus"]
+    out["config"] = {"workload": cut(f"3x3x3 apply_move + solved flag, {n} cubes/GPU/launch x {world} GPU(s), u8 SoA [54][N], ping-pong; "
+                                     + ("configs[1] shape at the metric's batch 4M" if n == N_CUBES else "configs[3] shape: 1M cubes per GPU" if n == 1 << 20 else "custom batch"), 200),
+                     **pick(full["config"], ("cubes_per_gpu", "total_cubes", "bytes_per_step_algorithmic", "parallelism", "process_group", "distinct_devices",
+                                             "shared_gpu_rehearsal"))}
+    r = full["roofline"]
+    out["roofline"] = pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_us", "launch_us_min", "launch_us_max", "launch_us_timed_region",
+                               "launch_batches", "launches_per_batch", "frac_timed_region", "frac_wall_clock", "frac_hbm_only", "algorithmic_bytes_per_launch",
+                               "served_by", "achievable_GBps", "frac_of_achievable", "device_copy_GBps", "frac_of_device_copy", "aggregate_GBps",
+                               "aggregate_frac_of_n_x_peak"))
+    out["roofline"]["frac_basis"] = "launch_us = median event-timed batch of K launches after the timed region"
+    out["roofline"]["traffic_source"] = "profiles/traffic.json (builder's rocprofv3 --pmc passes)" if r.get("traffic") is not None else None
+    if "cpu_baseline" in full:
+        c = full["cpu_baseline"]
+        out["cpu_baseline"] = pick(c, ("value", "unit", "cores", "kind", "single_core_steps_per_s", "numpy_env_1core_steps_per_s", "numpy_env_allcores_steps_per_s",
+                                       "numpy_env_processes"))
+        out["cpu_baseline"]["sample"] = cut(c.get("sample_short") or c.get("sample", ""))
+    if not (world > 1 or full["config"].get("process_group")):
+        out["config"]["pci_bus_id"] = full["per_gpu"][0]["pci_bus_id"] if full.get("per_gpu") else None
+    else:
+        out["per_gpu"] = [{"rank": p["rank"], "dev": p["device_index"], "pci": p["pci_bus_id"], "stream": p["stream_id"], "launch_us": sig(p["launch_us"], 5),
+                           "gsteps_per_s": sig(p["steps_per_s"] / 1e9, 5), "sha12": p["initial_state_sha256_first_cubes"][:12]} for p in full["per_gpu"]]
+    cf = full.get("configs")
+    if cf:                                                            # at most ten scalars of the other workloads; their records are in the full file
+        pc = {x["name"]: x for x in r.get("per_config", [])}
+        ap, c5 = cf.get("adi_pipeline", {}), cf.get("config5_mcts_4096_leaves", {})
+        ex = {"cfg2_1M_step_reward_frac": pc.get("cfg2 1M step+reward", {}).get("frac"),
+              "cfg3_adi_100kx30_frac": pc.get("cfg3 ADI 100k x 30", {}).get("frac"),
+              "cfg3_adi_100kx30_us": pc.get("cfg3 ADI 100k x 30", {}).get("launch_us"),
+              "dense_f32_1M_step_frac": pc.get("1M step+dense f32", {}).get("frac"),
+              "adi_pipeline_200x30_s": ap.get("200x30", {}).get("seconds"),
+              "adi_pipeline_100kx30_samples_per_s": ap.get("100000x30", {}).get("samples_per_s"),
+              "cfg5_leaves_step_hipgraph_us": c5.get("batched_mcts_leaves_step_with_d2h_hipgraph_us"),
+              "cfg5_serial_step_hipgraph_us": c5.get("hipgraph_serial_step_us"),
+              "reset_seeds_1M_k30_ms": cf.get("reset_seeds_1M_k30", {}).get("reset_ms"),
+              "facade_step_us": cf.get("facade_batch1", {}).get("CubeEnv.step_us")}
+        out["extras"] = {k: sig(v, 5) for k, v in ex.items() if v is not None}
+    if full.get("dry_run"):
+        out["dry_run"] = True
+    if full_path:
+        out["full_record"] = cut(full_path)
+    for key in ("roofline", "cpu_baseline"):
+        if key in out:
+            out[key] = {k: sig(v, 7) for k, v in out[key].items()}
+    return out
 
 
 if __name__ == "__main__":

@@ -48,8 +48,7 @@ def timeit(fn, iters=200, warm=20):
 def run(short=False, iters=None, sims=20):
     """-> dict of microsecond timings.  short: fewer repetitions (bench.py's default line); the lockstep-search legs always run.
     Legs: the kernels of one MCTS step on 4096 leaves (expansion, dense encode, net forward) one by one, as the serial sequence the
-    product launches (eager and as a hipGraph), ONE two-stream variant for BASELINE config 5's wording ("interleaved with the value-net
-    forward": it loses at this size and the product does not use it), then the product's lockstep search: device step, device step +
+    product launches (eager and as a hipGraph), then the product's lockstep search: device step, device step +
     upload + packed download, and whole simulations split into select / device + transfers / update."""
     import time
 
@@ -65,7 +64,6 @@ def run(short=False, iters=None, sims=20):
     ex = ops.expand_buffers(n, cs, dev, children=True, codes=True)
     pitch = ex["children"].shape[-1]
     onehot = torch.empty((n, 20, 24), dtype=torch.float32, device=dev)
-    side = torch.cuda.Stream(dev)
 
     def expand():
         ops.expand_children(leaves, n, cs, ex["children"], ex["child_solved"], ex["child_code"], pitch=pitch)
@@ -82,13 +80,6 @@ def run(short=False, iters=None, sims=20):
     def serial():
         expand(); encode(); forward()
 
-    def overlapped():
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            expand()
-        encode(); forward()
-        torch.cuda.current_stream().wait_stream(side)
-
     res = {
         "leaves": n, "children_per_step": n * 12,
         "expand_stickers_codes_flags_us": T(expand),
@@ -96,10 +87,9 @@ def run(short=False, iters=None, sims=20):
         "encode_dense_f32_us": T(encode),
         "forward_us": T(forward),
         "serial_step_us": T(serial),
-        "two_stream_step_us": T(overlapped),
     }
-    res["two_stream_note"] = ("expansion on a side stream next to encode + forward: the two cross-stream dependencies cost more than the ~7 us of expansion they "
-                              "could hide; BatchedMCTS runs everything on one stream")
+    # BASELINE config 5's "interleaved with the value-net forward" as two streams was measured in rounds 3-5 and lost (serial 164 us, two streams
+    # 207 us, hipGraph 123 us: EXPERIMENTS.md); the product runs one stream / one hipGraph and the leg is gone from the bench
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream(dev)
     s.wait_stream(torch.cuda.current_stream())

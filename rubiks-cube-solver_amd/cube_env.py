@@ -217,7 +217,7 @@ class CubeEnv:
         moves come from np.random.randint(action_dim, size=sample_scramble_count) on the global legacy
         RNG, exactly as the reference draws them; walks, expansion, one-hots and targets run on the GPU.  A sink with
         `append_batch` (replay.TensorReplayBuffer) receives the batch as tensors; anything else gets the reference's dicts."""
-        from .adi import AdiPlan, samples_to_dicts
+        from .adi import _module_device, _module_dtype, samples_to_dicts
 
         if sample_cube_count <= 0:
             return
@@ -227,14 +227,15 @@ class CubeEnv:
         if sample_scramble_count > 0:
             tensor_sink = hasattr(replay_buffer, "append_batch")         # replay.TensorReplayBuffer: no per-sample dicts
             # train.py:152-155 calls this every epoch with one shape and one model object: the buffers (and with adi_graph the
-            # captured hipGraph) of that shape are kept between calls
-            key = (id(model), sample_scramble_count, sample_cube_count, float(temperature), not tensor_sink, bool(self.adi_graph))
+            # captured hipGraph) of that shape are kept between calls -- ONE plan per env (up to the 1 GiB dense budget of device memory,
+            # about 150 MB at 200 x 30, held until close()).  The plan freezes the dtype the net computes in and where its parameters
+            # live, so both are part of the key: after an in-place model.half() / model.to(...) the next call builds a new plan
+            key = (id(model), sample_scramble_count, sample_cube_count, float(temperature), not tensor_sink, bool(self.adi_graph),
+                   str(_module_dtype(model)), str(_module_device(model, None)))
             plan = self._adi_plans.get(key)
             if plan is None or plan.model is not model:
                 self._adi_plans.clear()
-                plan = self._adi_plans[key] = AdiPlan(model, self.cube_size, sample_cube_count, sample_scramble_count, temperature,
-                                                      device=self._vec.device, model_device=self.device, want_state_dense=not tensor_sink,
-                                                      graph=bool(self.adi_graph))
+                plan = self._adi_plans[key] = self._new_adi_plan(model, sample_cube_count, sample_scramble_count, temperature, not tensor_sink)
             res = plan.run(actions)
             if tensor_sink:
                 replay_buffer.append_batch(res)
@@ -247,6 +248,12 @@ class CubeEnv:
             self._vec.init_state()
         self._sim_cache = None
         self._cube_cache = None
+
+    def _new_adi_plan(self, model, n_walks, depth, temperature, want_state_dense):
+        """The device plan behind get_random_samples (adi.AdiPlan: generator launch, one-hot blocks, the caller's net, target assembly)."""
+        from .adi import AdiPlan
+        return AdiPlan(model, self.cube_size, n_walks, depth, temperature, device=self._vec.device, model_device=self.device,
+                       want_state_dense=want_state_dense, graph=bool(self.adi_graph))
 
     def get_target_value(self, model, scramble_count, temperature):
         """(target_value, target_policy, error) of the CURRENT state (cube_env.py:196-252)."""
@@ -302,7 +309,7 @@ class CubeEnv:
 
     # mcts.py:37,96,101 deep-copies the env
     def __deepcopy__(self, memo):
-        other = object.__new__(CubeEnv)
+        other = object.__new__(type(self))         # a subclass stays itself through mcts.py's copies
         for k, v in self.__dict__.items():
             if k == "_vec":
                 other._vec = self._vec.clone(lean=True)

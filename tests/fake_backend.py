@@ -72,3 +72,54 @@ class HostLogicCubeEnv(CubeEnv):
 
     def _step_device(self, idx):
         return self._steps_device(bytes([idx]))
+
+    # get_random_samples / get_target_value on a machine without a GPU: the device plan and the one-launch expansion from the oracle
+    def _new_adi_plan(self, model, n_walks, depth, temperature, want_state_dense):
+        return OracleAdiPlan(model, self.cube_size, n_walks, depth, temperature, want_state_dense, self.device)
+
+    def expand_host(self, dense=False):
+        cs = self.cube_size
+        children, child_code, child_solved = _ORC.expand(cs, self._vec.state)
+        own = _ORC.encode(cs, self._vec.state)[0][0].tobytes()
+        out = (own, child_code[0].copy(), child_solved[0].astype(bool))
+        if dense:
+            out += (_ORC.encode(cs, children[0])[1].astype(np.uint8),)
+        return out
+
+
+class OracleAdiPlan:
+    """CPU stand-in of adi.AdiPlan (same result dict, same `model` attribute) for the host-logic tests: walks and expansion from the
+    oracle, the caller's model called sample by sample exactly as cube_env.py:239-251 does (the A children, then the state), so the
+    floats are the reference's own.  What it lets a CPU test exercise is everything AROUND the plan in CubeEnv.get_random_samples:
+    the legacy-RNG draws, the plan cache, samples_to_dicts, the sink protocol, the env's final state."""
+
+    def __init__(self, model, cube_size, n_walks, depth, temperature, want_state_dense, model_device):
+        self.model, self.cs, self.W, self.D, self.T = model, cube_size, n_walks, depth, temperature
+        self.want_state_dense, self.mdev = want_state_dense, model_device
+
+    @torch.no_grad()
+    def run(self, actions):
+        cs, W, D = self.cs, self.W, self.D
+        R, C = STATE_DIM[cs]
+        res = _ORC.adi(cs, W, D, actions_in=np.asarray(actions, np.uint8), want_children=True)
+        S, A = res["parents"].shape[-1], res["child_solved"].shape[-1]
+        state = _ORC.encode(cs, res["parents"].reshape(-1, S))[1].reshape(W, D, R, C)
+        kids = _ORC.encode(cs, res["children"].reshape(-1, S))[1].reshape(W, D, A, R, C)
+        tv, tp, err = np.zeros((W, D), np.float32), np.zeros((W, D), np.int32), np.zeros((W, D), np.float64)
+        for w in range(W):
+            for d in range(D):
+                solved = res["child_solved"][w, d]
+                if solved.any():                                              # cube_env.py:229-232
+                    v, a = 1.0, int(np.argmax(solved))
+                else:                                                         # cube_env.py:239-246
+                    nv = self.model(torch.from_numpy(kids[w, d]).float().to(self.mdev))[0].squeeze(dim=-1) + torch.tensor([-1.0] * A, device=self.mdev)
+                    v, a = torch.max(nv, -1, keepdim=True)
+                    v, a = v.item(), a.item()
+                own = self.model(torch.from_numpy(state[w, d]).float().to(self.mdev))[0]
+                tv[w, d], tp[w, d], err[w, d] = v, a, abs(own.item() - v) * ((d + 1) ** (-1 * self.T))
+        out = {"state_code": torch.from_numpy(res["parent_code"]), "target_value": torch.from_numpy(tv), "target_policy": torch.from_numpy(tp),
+               "error": torch.from_numpy(err), "actions": torch.from_numpy(res["actions"]),
+               "scramble_count": torch.arange(1, D + 1, dtype=torch.int64).expand(W, D).contiguous()}
+        if self.want_state_dense:
+            out["state"] = torch.from_numpy(state.astype(np.uint8))
+        return out

@@ -552,3 +552,65 @@ def test_eight_rank_streams_and_shards(tmp_path):
     for k, r in enumerate(rs):
         assert r["first_actions"] == orc.rng_actions(77, d.rng_stream(k), 0, 6, 12).tolist(), k
     assert len({tuple(r["first_actions"]) for r in rs}) == 8
+
+
+def test_reference_callers_run_unmodified_against_the_product_cube_env():
+    """The drop-in claim, executed: the REFERENCE's own mcts.MCTS.train (mcts.py:36-154), train.validation (train.py:167-198),
+    test.trial (test.py:103-158, plain / masked / MCTS) and utils.ReplayBuffer + DataLoader (utils.py:203-270,296-303) are imported
+    unmodified (make_golden.py's three harness shims) and driven with the product's CubeEnv class -- here its host logic over the
+    oracle backend, tests/fake_backend.HostLogicCubeEnv -- and every observable (simulations used, action lists, node statistics,
+    every env.step validation issues, solve steps, the replay deque, prioritised indices, __getitem__ dtypes, DataLoader order,
+    get_target_value) equals what the reference computed with its OWN env (G5, G8, G9, G11, G12).  27 checks; runs in a child
+    process because the shims rebind `gym`, numpy.int and put the reference's `utils` / `test` / `model` modules on sys.path.
+    The reference never travels: skipped where /root/reference is absent (the GPU box)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference/gym-cube"):
+        pytest.skip("the reference is only present in the build container")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-B", os.path.join(root, "tests", "golden", "run_reference_callers.py")],
+                         capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["failed"] == [] and len(d["checks"]) == 27 and all(d["checks"].values())
+    assert d["env_class"] == "rubiks_cube_solver_amd.cube_env" and d["reference_modules"] == ["mcts", "model", "test", "train", "utils"]
+
+
+def test_cube_env_subclass_survives_deepcopy_and_plan_key():
+    """mcts.py:37,96,101 deep-copies the env 14 times per simulation: a subclass must stay itself (round 6: the copy was a plain
+    CubeEnv, found by running the reference's MCTS against HostLogicCubeEnv).  get_random_samples keeps one plan per call shape AND
+    per (dtype, device) of the model (an in-place model.half() / .to() must not meet the stale plan)."""
+    import copy
+    env = _env(3)
+    assert type(copy.deepcopy(env)) is type(env)
+    made = []
+    orig = type(env)._new_adi_plan
+
+    def counting(self, model, *a):
+        made.append(str(next(model.parameters()).dtype))
+        return orig(self, model, *a)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(480, 1)
+
+        def forward(self, x):
+            if x.dim() == 2:
+                x = x.unsqueeze(0)
+            return self.lin(x.reshape(x.shape[0], -1).to(self.lin.weight.dtype)).float(), torch.zeros(x.shape[0], 12)
+
+    net = Net()
+    type(env)._new_adi_plan = counting
+    try:
+        sink = []
+        env.get_random_samples(sink, net, 3, 2, 1.0)
+        env.get_random_samples(sink, net, 3, 2, 1.0)                     # same shape, same model: the kept plan
+        assert made == ["torch.float32"] and len(sink) == 12
+        net.bfloat16()                                                   # in place: same object, other dtype
+        env.get_random_samples(sink, net, 3, 2, 1.0)
+        assert made == ["torch.float32", "torch.bfloat16"] and len(sink) == 18 and len(env._adi_plans) == 1
+    finally:
+        type(env)._new_adi_plan = orig

@@ -72,6 +72,12 @@ extern "C" {
 /* Library / ABI version (major*100 + minor). */
 int rc_version(void);
 
+/* Identity of the sources this binary was built from: the first 16 hex digits of a sha256 over rubikhip.hip, rc_device.h,
+ * rc_tables.h and this header (rubiks-cube-solver_amd/_build.py), passed as -DRC_SRC_HASH at build time; "unhashed" for a build
+ * that was not given one.  The Python binding compares it with the tree's sources and refuses a stale library.  Static storage.
+ * (Tooling; no reference counterpart.) */
+const char *rc_build_id(void);
+
 /* Check that `device` is a gfx950 GPU, make the code object resident there and clear its status
  * word.  Idempotent; the caller's current device is not changed (kernels run on the device of the
  * stream / current device the caller set, one process per GPU).  Replaces: importing py333 (module-level table construction,
@@ -208,6 +214,13 @@ int rc_onehot_from_code(const uint8_t *code, int64_t n_cubes, int64_t code_pitch
                         void *onehot, int fmt, void *stream);
 int rc_onehot_from_code_ex(const uint8_t *code, int64_t n_cubes, int64_t code_pitch, int cube_size,
                            void *onehot, int fmt, void *stream, int variant);
+/* The same for n_blocks EQUALLY TILED code buffers in one launch: block b is read at code + b * src_block_stride bytes (n_cubes cubes,
+ * tiling code_pitch) and written at onehot + b * dst_block_stride cubes (dst_block_stride >= n_cubes; every block 16-byte aligned).
+ * What the 2x2x2 ADI pipeline needs: the A child-code buffers of each depth ([depth][A][tile][SLOTS][pitch] of rc_adi_generate) become
+ * the packed [depth * A][dst_block_stride] input of ONE forward of the value net (cube_env.py:239-251 evaluates 12 + 1 rows at a time)
+ * instead of blocks padded to whole tiles (the 3x3x3 pipeline uses rc_onehot_from_family_depths). */
+int rc_onehot_from_code_blocks(const uint8_t *code, int64_t n_cubes, int64_t code_pitch, int cube_size, void *onehot, int fmt,
+                               int n_blocks, int64_t src_block_stride, int64_t dst_block_stride, void *stream);
 
 /* All A children of every cube.  Outputs use one tiling (pitch_out, tiles = ceil(n / pitch_out)
  * when n > pitch_out, else 1), child-major:

@@ -36,6 +36,10 @@ extern "C" {
 typedef struct rc_tree rc_tree;
 
 /* n_roots independent trees; n_actions = 12 | 6, n_slots = 20 | 7 (key bytes).  NULL on bad arguments. */
+/* Identity of the sources this binary was built from (sha256 over rc_tree.cpp + this header, first 16 hex digits, passed as
+ * -DRC_SRC_HASH by __graft_entry__.build_tree); "unhashed" otherwise.  Static storage. */
+const char *rc_tree_build_id(void);
+
 rc_tree *rc_tree_create(int n_roots, int n_actions, int n_slots, double cpuct, double virtual_loss, double value_min);
 void rc_tree_destroy(rc_tree *t);
 /* OpenMP threads for select / update (default 1; pass the job's CPU share, not the host's thread count).  Returns the

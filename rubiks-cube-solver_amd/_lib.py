@@ -31,6 +31,7 @@ class RubikHipError(RuntimeError):
 def _declare(L):
     vp, i64, i32, u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64
     L.rc_version.restype = i32
+    L.rc_build_id.restype = ctypes.c_char_p
     L.rc_last_error.restype = ctypes.c_char_p
     L.rc_init.argtypes = [i32]
     L.rc_get_tables.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
@@ -50,6 +51,7 @@ def _declare(L):
     L.rc_encode.argtypes = [vp, i64, i64, i32, vp, i32, i64, vp]
     L.rc_onehot_from_code.argtypes = [vp, i64, i64, i32, vp, i32, vp]
     L.rc_onehot_from_code_ex.argtypes = [vp, i64, i64, i32, vp, i32, vp, i32]
+    L.rc_onehot_from_code_blocks.argtypes = [vp, i64, i64, i32, vp, i32, i32, i64, i64, vp]
     L.rc_expand_children.argtypes = [vp, i64, i64, i32, vp, vp, vp, i64, vp]
     L.rc_expand_children_ex.argtypes = [vp, i64, i64, i32, vp, vp, vp, i64, vp, i32]
     L.rc_adi_generate.argtypes = [u64, u64, i64, i64, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -71,7 +73,7 @@ def _declare(L):
                  "rc_legacy_scramble_actions", "rc_is_solved", "rc_encode", "rc_onehot_from_code", "rc_expand_children",
                  "rc_expand_children_ex", "rc_adi_generate", "rc_adi_generate_ex", "rc_adi_targets", "rc_read_status",
                  "rc_describe_dispatch", "rc_facade_release", "rc_onehot_from_code_ex", "rc_apply_moves_ws", "rc_encode_ws", "rc_adi_generate_family", "rc_family_layout",
-                 "rc_onehot_from_family", "rc_adi_targets_depths", "rc_onehot_from_family_depths", "rc_legacy_scramble_actions_ex", "rc_host_alias", "rc_scramble_from", "rc_search_pack"):
+                 "rc_onehot_from_family", "rc_adi_targets_depths", "rc_onehot_from_family_depths", "rc_legacy_scramble_actions_ex", "rc_host_alias", "rc_scramble_from", "rc_search_pack", "rc_onehot_from_code_blocks"):
         getattr(L, name).restype = i32
 
 
@@ -86,9 +88,21 @@ def lib():
                         f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
                 L = ctypes.CDLL(LIB_PATH)
+                if not hasattr(L, "rc_build_id"):
+                    raise RubikHipError(f"{LIB_PATH} predates rc_build_id (ABI < 600): rebuild it with __graft_entry__.build()")
                 _declare(L)
+                from . import _build
+                try:                                                 # the binary must be the tree's sources (RC_ALLOW_STALE=1: A/B experiments)
+                    _build.check_loaded(LIB_PATH, L.rc_build_id().decode(), _build.HIP_SOURCES)
+                except RuntimeError as e:
+                    raise RubikHipError(str(e)) from None
                 _lib = L
     return _lib
+
+
+def build_id() -> str:
+    """The source hash the loaded library was built from (rc_build_id)."""
+    return lib().rc_build_id().decode()
 
 
 def check(rc):

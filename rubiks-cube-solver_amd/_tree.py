@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librubiktree.so")
+LIB_PATH = os.environ.get("RUBIKTREE_LIB") or os.path.join(_HERE, "librubiktree.so")   # env override: sanitizer builds (tools/sanitize_cpu.sh)
 _lib = None
 
 
@@ -21,6 +21,9 @@ def tree_lib():
             raise RuntimeError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
         L = ctypes.CDLL(LIB_PATH)
         vp, i32, dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+        from . import _build
+        L.rc_tree_build_id.restype = ctypes.c_char_p
+        _build.check_loaded(LIB_PATH, L.rc_tree_build_id().decode(), _build.TREE_SOURCES)      # a stale build is refused, not used
         L.rc_tree_create.restype = vp
         L.rc_tree_create.argtypes = [i32, i32, i32, dbl, dbl, dbl]
         L.rc_tree_destroy.argtypes = [vp]

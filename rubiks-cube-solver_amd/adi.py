@@ -2,7 +2,7 @@
 
 Device work (librubikhip.so): the random walks and their 12-child expansion (rc_adi_generate_family: the 51-byte family record
 per state; 2x2x2: rc_adi_generate with codes), the dense one-hots the value net reads (rc_onehot_from_family_depths /
-rc_onehot_from_code) and the target assembly (rc_adi_targets_depths).  The value net itself is the caller's unmodified torch module
+rc_onehot_from_code_blocks) and the target assembly (rc_adi_targets_depths).  The value net itself is the caller's unmodified torch module
 (model.py:31-45).
 
 Shape of one call (AdiPlan): ONE generator launch per chunk of walks, then per GROUP of depths one launch that writes the
@@ -94,12 +94,12 @@ class AdiPlan:
             pitch = _lib.pitch_for(wc) if wc <= ops.ADI_TILE else ops.ADI_TILE
             bs = -(-wc // 8) * 8
             return pitch, bs, (self.A + 1) * bs
-        # 2x2x2: a depth's A child buffers (and the parents of consecutive depths) are read as ONE tiled code buffer, which needs a
-        # power-of-two pitch >= 512; the block stride is then the padded walk count tiles * pitch: take the tile size that pads least
-        # (20 000 walks: 40 tiles of 512 = 20 480 rows per block instead of 2 x 16 384), the larger one on ties
-        pitch = min((1 << lg for lg in range(14, 8, -1)), key=lambda t: -(-max(wc, 1) // t) * t)
-        p = ops._tiles_of(wc, pitch) * pitch
-        return pitch, p, (self.A + 1) * p
+        # 2x2x2 (no family record): the A child-code buffers of every depth and the parent-code buffers are equally tiled, so ONE
+        # rc_onehot_from_code_blocks launch each packs them into blocks of ceil16(wc) rows ([depth][A][bs] children, then [depth][bs]
+        # parents) -- round 5 fed the net blocks padded to whole tiles of >= 512 walks (200 walks: 2.56 x the rows)
+        pitch = _lib.pitch_for(wc) if wc <= ops.ADI_TILE else ops.ADI_TILE
+        bs = -(-wc // 16) * 16
+        return pitch, bs, (self.A + 1) * bs
 
     def _chunk_buffers(self, wc):
         pitch, bs, _ = self._geometry(wc)
@@ -122,13 +122,13 @@ class AdiPlan:
             if self.fam:
                 ops.onehot_from_family(bufs["family"][g0:g0 + gc], wc, cs, x, block_stride=bs, n_depths=gc)
             else:
-                ops.onehot_from_code(bufs["child_code"][g0:g0 + gc].view(gc * A * tiles, SL, pitch), gc * A * p, cs, x[:gc * A * p])
-                ops.onehot_from_code(bufs["parent_code"][g0:g0 + gc].view(gc * tiles, SL, pitch), gc * p, cs, x[gc * A * p:])
+                ops.onehot_from_code_blocks(bufs["child_code"][g0:g0 + gc].view(gc * A, tiles, SL, pitch), wc, cs, x[:gc * A * bs], bs)
+                ops.onehot_from_code_blocks(bufs["parent_code"][g0:g0 + gc], wc, cs, x[gc * A * bs:], bs)
             v = self.model(x if self.mdev == dev else x.to(self.mdev))[0].reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
             if self.fam:                                           # [depth][A children, parent][bs]
                 cv, cvd, pv, pvd = v, (A + 1) * bs, v[A * bs:], (A + 1) * bs
-            else:                                                  # [depth][A][p] children, then [depth][p] parents
-                cv, cvd, pv, pvd = v, A * p, v[gc * A * p:], p
+            else:                                                  # [depth][A][bs] children, then [depth][bs] parents
+                cv, cvd, pv, pvd = v, A * bs, v[gc * A * bs:], bs
             ops.adi_targets_depths(cv, cvd, bs, bufs["child_solved"][g0:g0 + gc], pv, pvd, self.weights[g0:g0 + gc], wc, gc, cs,
                                    tv[:, g0:], tp[:, g0:], err[:, g0:])
         # walk-major copies of the generator's rows: parent codes (the sample states) and the moves
@@ -194,6 +194,7 @@ class AdiPlan:
 
 
 _plans = {}          # adi_samples(graph=True): captured plans per call shape, so that repeated calls replay instead of re-capturing
+MAX_KEPT_PLANS = 4   # each holds a reference to its model, its static buffers (dense: up to dense_budget_bytes) and the graph's private pool
 
 
 def adi_samples(model, cube_size, n_walks, depth, temperature, device="cuda", model_device=None, actions=None,
@@ -204,18 +205,23 @@ def adi_samples(model, cube_size, n_walks, depth, temperature, device="cuda", mo
     dense_dtype: dtype of the one-hot stream fed to `model` (default: float32, or the dtype of the model's first floating-point
     parameter when that is bfloat16 / float16); the returned values are float32 either way.
     graph: keep the plan of this call shape (static buffers + the captured hipGraph of everything behind the generator launch) in a
-    module-level cache and replay it on the next call with the same model object and shape; results are copies either way."""
+    module-level cache and replay it on the next call with the same model object and shape; results are copies either way.  The cache
+    holds the MAX_KEPT_PLANS most recently used plans (each pins its model, up to dense_budget_bytes of device memory and the captured
+    graph's activations); release_plans() drops them all."""
     if not graph:
         return AdiPlan(model, cube_size, n_walks, depth, temperature, device, model_device, dense_budget_bytes, want_state_dense,
                        dense_dtype).run(actions, seed, stream_id, walk_offset)
     key = (id(model), cube_size, int(n_walks), int(depth), float(temperature), str(torch.device(device)), str(model_device), int(dense_budget_bytes),
-           bool(want_state_dense), str(dense_dtype))
-    plan = _plans.get(key)
-    if plan is None or plan.model is not model:
-        if len(_plans) >= 8:
-            _plans.pop(next(iter(_plans)))
-        plan = _plans[key] = AdiPlan(model, cube_size, n_walks, depth, temperature, device, model_device, dense_budget_bytes, want_state_dense,
-                                     dense_dtype, graph=True)
+           bool(want_state_dense), str(dense_dtype), str(_module_dtype(model)), str(_module_device(model, None)))   # a plan freezes the net's dtype and device
+    plan = _plans.pop(key, None)                      # re-inserted below: the dict's order is the order of last use (LRU)
+    if plan is not None and plan.model is not model:
+        plan = None
+    if plan is None:
+        while len(_plans) >= MAX_KEPT_PLANS:
+            _plans.pop(next(iter(_plans)))            # the least recently used plan, not the oldest one: the hot shape stays captured
+        plan = AdiPlan(model, cube_size, n_walks, depth, temperature, device, model_device, dense_budget_bytes, want_state_dense,
+                       dense_dtype, graph=True)
+    _plans[key] = plan
     return plan.run(actions, seed, stream_id, walk_offset, clone=True)
 
 

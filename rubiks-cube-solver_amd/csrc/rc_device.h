@@ -724,11 +724,11 @@ __device__ __forceinline__ void dense_write_333(const uint8_t *lds_code, int tp,
 // so an element costs one LDS byte read and one compare.  The generic loop below re-derives cube / piece / slot / orientation with four
 // divisions PER ELEMENT: 1M cubes ran at 0.66 (f32), 0.45 (16-bit), 0.23 (u8) of the HBM peak, falling with the element size --
 // instruction-bound, not store-bound (profiles/r05_dense222.json).
-template <class T, class E, int NT>
+template <class T, class E, int NT, int U = 1>
 __device__ __forceinline__ void dense_write_222(const uint8_t *lds_code, int tp, E *out, int ncubes, int tid) {
     static_assert(T::SIZE == 2 && T::R * T::C == 147);
     constexpr int EPT = 16 / (int)sizeof(E), CPP = EPT, NCH = 147, PPI = NT / NCH;   // CPP cubes * 147 elements = NCH chunks; PPI passes per round
-    static_assert(PPI >= 1);
+    static_assert(PPI >= 1 && U >= 1);
     const int q = tid / NCH, t = tid - q * NCH;                                    // pass of the round, chunk of the pass
     if (q >= PPI) return;
     uint32_t off[EPT], want[EPT];
@@ -741,31 +741,59 @@ __device__ __forceinline__ void dense_write_222(const uint8_t *lds_code, int tp,
     }
     const uint32_t total = (uint32_t)ncubes * 147u;
     const __amdgpu_buffer_rsrc_t srd = make_srd(out);                             // `out` is workgroup-uniform
-    for (int base = 0; base + q * CPP < ncubes; base += CPP * PPI) {              // (cubes past ncubes: stale but in-bounds tile bytes, never stored)
-        uint32_t w[4] = {0u, 0u, 0u, 0u};
+    // U rounds per loop iteration (software pipeline, like dense_write_333): the LDS bytes of all U rounds are read before the first
+    // of their stores is issued.  Cubes past ncubes: stale but in-bounds tile bytes (the tile width is a multiple of U * CPP * PPI
+    // for every shipped shape, and tp = TILE + 4 covers CPP - 1 <= 3 more for the f32 pass), never stored.
+    for (int base = 0; base + q * CPP < ncubes; base += U * CPP * PPI) {
+        uint32_t w[U][4];
 #pragma unroll
-        for (int j = 0; j < EPT; ++j) {
-            const uint32_t one = (uint32_t)lds_code[off[j] + base] == want[j] ? One<E>::v : 0u;
-            w[j * (int)sizeof(E) / 4] |= one << (8 * ((j * (int)sizeof(E)) & 3));
+        for (int r = 0; r < U; ++r) {
+            w[r][0] = w[r][1] = w[r][2] = w[r][3] = 0u;
+            if (U > 1 && base + r * CPP * PPI + q * CPP >= ncubes) continue;       // a round past the tile: nothing to read or store
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                const uint32_t one = (uint32_t)lds_code[off[j] + base + r * CPP * PPI] == want[j] ? One<E>::v : 0u;
+                w[r][j * (int)sizeof(E) / 4] |= one << (8 * ((j * (int)sizeof(E)) & 3));
+            }
         }
-        const uint32_t e0 = (uint32_t)(base + q * CPP) * 147u + (uint32_t)t * EPT;
-        if (e0 + EPT <= total) {
-            Pk<4> u;
-            u.d[0] = w[0]; u.d[1] = w[1]; u.d[2] = w[2]; u.d[3] = w[3];
-            bst<4, kAuxStreamStore>(srd, e0 * (uint32_t)sizeof(E), 0, u);
-        } else {                                                                  // ragged end of the last pass
-            for (uint32_t j = 0; e0 + j < total; ++j) {
-                const uint32_t bit = j * (uint32_t)sizeof(E) * 8u;
-                out[e0 + j] = __builtin_bit_cast(E, (typename UIntOf<sizeof(E)>::type)(w[bit >> 5] >> (bit & 31u)));
+#pragma unroll
+        for (int r = 0; r < U; ++r) {
+            const int first = base + r * CPP * PPI + q * CPP;                     // first cube of this thread's pass
+            if (first >= ncubes) break;
+            const uint32_t e0 = (uint32_t)first * 147u + (uint32_t)t * EPT;
+            if (e0 + EPT <= total) {
+                Pk<4> u;
+                u.d[0] = w[r][0]; u.d[1] = w[r][1]; u.d[2] = w[r][2]; u.d[3] = w[r][3];
+                bst<4, kAuxStreamStore>(srd, e0 * (uint32_t)sizeof(E), 0, u);
+            } else {                                                              // ragged end of the last pass
+                for (uint32_t j = 0; e0 + j < total; ++j) {
+                    const uint32_t bit = j * (uint32_t)sizeof(E) * 8u;
+                    out[e0 + j] = __builtin_bit_cast(E, (typename UIntOf<sizeof(E)>::type)(w[r][bit >> 5] >> (bit & 31u)));
+                }
             }
         }
     }
 }
 
+// 2x2x2 float32 shape (round 6 A/B at 2^12 .. 2^22 cubes, tools/exp/d222_f32.py, profiles/r06_d222_f32.json; fraction of the HBM peak at
+// 2^16+3 / 2^20 / 2^22 cubes, 64-cube tiles): the generic loop on 256 threads 0.49 / 0.65 / 0.63; the fixed mapping on 320 threads 0.41 /
+// 0.49 / 0.48 (2 or 4 rounds in flight: the same), on 448 threads 0.43 / 0.54 / 0.47, on 640 threads 0.58 / 0.67 / 0.67.  Cutting the
+// instructions per store by 4 x does not help by itself -- the launch is not VALU-bound for f32; what helps is a longer contiguous burst
+// per workgroup round (588 lanes x 16 B = 9.4 KB).  RC_D222_F32 = 0: the generic loop; = NT: dense_write_222 on NT threads with
+// RC_D222_F32_PIPE rounds in flight.
+#ifndef RC_D222_F32
+#define RC_D222_F32 640
+#endif
+#ifndef RC_D222_F32_PIPE
+#define RC_D222_F32_PIPE 2
+#endif
+
 template <class T, class E>
 __device__ __forceinline__ void dense_write(const uint8_t *lds_code, int tp, E *out, int ncubes, int tid, int nthreads) {
     if constexpr (T::SIZE == 3) {
         if (nthreads == 256) { dense_write_333<T, E>(lds_code, tp, out, ncubes, tid); return; }
+    } else if constexpr (sizeof(E) == 4 && RC_D222_F32 != 0) {
+        if (nthreads == RC_D222_F32) { dense_write_222<T, E, RC_D222_F32, RC_D222_F32_PIPE>(lds_code, tp, out, ncubes, tid); return; }
     } else {
         if (nthreads == 320) { dense_write_222<T, E, 320>(lds_code, tp, out, ncubes, tid); return; }
     }

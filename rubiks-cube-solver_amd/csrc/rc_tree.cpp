@@ -132,7 +132,16 @@ int32_t descend_begin(rc_tree *t, int r, Mt *gen) {
 
 }  // namespace
 
+#ifndef RC_SRC_HASH
+#define RC_SRC_HASH unhashed
+#endif
+#define RC_STR2(x) #x
+#define RC_STR(x) RC_STR2(x)
+static const char k_build_id[] = "rc-build-id:" RC_STR(RC_SRC_HASH);
+
 extern "C" {
+
+const char *rc_tree_build_id(void) { return k_build_id + 12; }
 
 rc_tree *rc_tree_create(int n_roots, int n_actions, int n_slots, double cpuct, double virtual_loss, double value_min) {
     if (n_roots <= 0 || n_actions <= 0 || n_actions > kMaxA || n_slots <= 0 || n_slots > kMaxSlots) return nullptr;

@@ -203,10 +203,11 @@ __global__ void __launch_bounds__(BLOCK) k_step(StepArgs a) {
 
 // ----------------------------------------------------------- step + dense one-hot (LDS stage)
 constexpr int kDenseBlock = 256;
-// 2x2x2, 1- and 2-byte elements: 320 threads -- the dense writer's unit is a 147-chunk pass (dense_write_222) and 294 of 320 lanes cover
-// two of them per round.  f32 keeps the generic 256-thread loop: it is store-bound there (0.66 against 0.54 with the pass form at 1M
-// cubes), the narrow formats are instruction-bound in it (0.45 / 0.23 against 0.53 / 0.52; profiles/r05_dense222.json).
-template <class T, class E> constexpr int kDenseThreads = (T::SIZE == 2 && sizeof(E) <= 2) ? 320 : kDenseBlock;
+// 2x2x2: the dense writer's unit is a 147-chunk pass (dense_write_222).  1- and 2-byte elements: 320 threads, 294 of them cover two passes
+// per round (instruction-bound in the generic loop: 0.45 / 0.23 against 0.53 / 0.52; profiles/r05_dense222.json).  f32: 640 threads, 588
+// of them cover four passes per round (rc_device.h RC_D222_F32: 0.67 against 0.65 for the generic 256-thread loop at 1M cubes, 0.58 against
+// 0.49 at 64k; profiles/r06_d222_f32.json).
+template <class T, class E> constexpr int kDenseThreads = (T::SIZE == 2 && sizeof(E) <= 2) ? 320 : (T::SIZE == 2 && RC_D222_F32 != 0) ? RC_D222_F32 : kDenseBlock;
 // TILE cubes per workgroup (64 | 256): the first TILE/4 lanes compute the pack's codes, then
 // all 256 threads stream the dense rows.  Small tiles keep small batches (MCTS leaves) spread over
 // the chip: 4096 cubes are 64 workgroups at TILE = 64 but only 4 at TILE = 1024.
@@ -269,10 +270,15 @@ __global__ void __launch_bounds__((kDenseThreads<T, E>)) k_step_dense(StepArgs a
 }
 
 template <class T, class E, int TILE>
-__global__ void __launch_bounds__((kDenseThreads<T, E>)) k_code_to_dense(const uint8_t *code, int64_t n, int64_t code_pitch, int shift, E *dense) {
+__global__ void __launch_bounds__((kDenseThreads<T, E>)) k_code_to_dense(const uint8_t *code, int64_t n, int64_t code_pitch, int shift, E *dense,
+                                                                         int64_t src_block_stride = 0, int64_t dst_block_stride = 0) {
     constexpr int TP = TILE + 4;
     __shared__ __attribute__((aligned(16))) uint8_t lds_code[T::SLOTS * TP];
     const uint32_t lo = threadIdx.x * 4;
+    // rc_onehot_from_code_blocks: blockIdx.y = one of several equally tiled code buffers (src_block_stride bytes apart), written to its own
+    // block of the output (dst_block_stride cubes apart); a plain launch has gridDim.y == 1 and both strides 0
+    code += (int64_t)blockIdx.y * src_block_stride;
+    dense += (int64_t)blockIdx.y * dst_block_stride * (T::R * T::C);
     for (int64_t tile0 = (int64_t)blockIdx.x * TILE; tile0 < n; tile0 += (int64_t)gridDim.x * TILE) {
 #if RC_DENSE_CTRL < 2
         if (lo < TILE && tile0 + lo < n) {
@@ -356,7 +362,7 @@ __global__ void __launch_bounds__(kWideBlock) k_code_to_dense_wide(const uint8_t
 // issued together with the kernel arguments, and a lane picks its slot's byte with two 64-bit selects and a shift.  Round 4 read the
 // table with a per-lane byte load, a second dependent memory round trip in front of every code gather, and a front workgroup LIVES
 // for its round trips: 0.52 of the HBM peak at 43008 walks against 0.95 for the plain code -> dense form (profiles/r05_family_front.json).
-struct FamilyRowWords {
+struct alignas(32) FamilyRowWords {      // read as u32x8 (32-byte vectors): the symbol must be placed on that alignment
     uint32_t w[Cube3::A + 1][8];
     constexpr FamilyRowWords() : w{} {
         for (int a = 0; a <= Cube3::A; ++a)
@@ -1372,15 +1378,16 @@ int launch_dense(const StepArgs &a, void *onehot, int fmt, hipStream_t st, int v
 }
 
 template <class T, int TILE>
-int launch_code_to_dense(const uint8_t *code, int64_t n, int64_t code_pitch, int sh, void *onehot, int fmt, hipStream_t st) {
+int launch_code_to_dense(const uint8_t *code, int64_t n, int64_t code_pitch, int sh, void *onehot, int fmt, hipStream_t st,
+                         int n_blocks = 1, int64_t src_bs = 0, int64_t dst_bs = 0) {
     int64_t blocks = (n + TILE - 1) / TILE;
     RC_GRID(blocks);
     blocks = dense_grid(blocks, fmt);
-    const dim3 g((unsigned)blocks);
-    if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_code_to_dense<T, uint8_t, TILE>), g, dim3(kDenseThreads<T, uint8_t>), 0, st, code, n, code_pitch, sh, static_cast<uint8_t *>(onehot));
-    else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_code_to_dense<T, uint16_t, TILE>), g, dim3(kDenseThreads<T, uint16_t>), 0, st, code, n, code_pitch, sh, static_cast<uint16_t *>(onehot));
-    else if (fmt == RC_FMT_BF16) hipLaunchKernelGGL((k_code_to_dense<T, Bf16, TILE>), g, dim3(kDenseThreads<T, Bf16>), 0, st, code, n, code_pitch, sh, static_cast<Bf16 *>(onehot));
-    else hipLaunchKernelGGL((k_code_to_dense<T, float, TILE>), g, dim3(kDenseThreads<T, float>), 0, st, code, n, code_pitch, sh, static_cast<float *>(onehot));
+    const dim3 g((unsigned)blocks, (unsigned)n_blocks);
+    if (fmt == RC_FMT_U8) hipLaunchKernelGGL((k_code_to_dense<T, uint8_t, TILE>), g, dim3(kDenseThreads<T, uint8_t>), 0, st, code, n, code_pitch, sh, static_cast<uint8_t *>(onehot), src_bs, dst_bs);
+    else if (fmt == RC_FMT_F16) hipLaunchKernelGGL((k_code_to_dense<T, uint16_t, TILE>), g, dim3(kDenseThreads<T, uint16_t>), 0, st, code, n, code_pitch, sh, static_cast<uint16_t *>(onehot), src_bs, dst_bs);
+    else if (fmt == RC_FMT_BF16) hipLaunchKernelGGL((k_code_to_dense<T, Bf16, TILE>), g, dim3(kDenseThreads<T, Bf16>), 0, st, code, n, code_pitch, sh, static_cast<Bf16 *>(onehot), src_bs, dst_bs);
+    else hipLaunchKernelGGL((k_code_to_dense<T, float, TILE>), g, dim3(kDenseThreads<T, float>), 0, st, code, n, code_pitch, sh, static_cast<float *>(onehot), src_bs, dst_bs);
     RC_HIP(hipGetLastError());
     return RC_OK;
 }
@@ -1607,7 +1614,17 @@ int launch_adi(AdiArgs a, hipStream_t st) {
 // =============================================================================== C ABI
 extern "C" {
 
-int rc_version(void) { return 500; }
+int rc_version(void) { return 600; }
+
+// the hash of the sources this binary was compiled from (__graft_entry__.build passes -DRC_SRC_HASH=<16 hex digits>); a plain
+// `hipcc -c` of this file still compiles and reports "unhashed", which the Python binding refuses as stale
+#ifndef RC_SRC_HASH
+#define RC_SRC_HASH unhashed
+#endif
+#define RC_STR2(x) #x
+#define RC_STR(x) RC_STR2(x)
+static const char k_build_id[] = "rc-build-id:" RC_STR(RC_SRC_HASH);
+const char *rc_build_id(void) { return k_build_id + 12; }
 
 const char *rc_last_error(void) { return t_err; }
 
@@ -1870,6 +1887,26 @@ int rc_onehot_from_code_ex(const uint8_t *code, int64_t n, int64_t code_pitch, i
 
 int rc_onehot_from_code(const uint8_t *code, int64_t n, int64_t code_pitch, int cube_size, void *onehot, int fmt, void *stream) {
     return rc_onehot_from_code_ex(code, n, code_pitch, cube_size, onehot, fmt, stream, 0);
+}
+
+int rc_onehot_from_code_blocks(const uint8_t *code, int64_t n, int64_t code_pitch, int cube_size, void *onehot, int fmt, int n_blocks,
+                               int64_t src_block_stride, int64_t dst_block_stride, void *stream) {
+    RC_NEED_INIT();
+    const int sh = tile_shift(code_pitch, n, 20);
+    if (!code || !aligned16(code) || n < 0 || sh < 0) return fail(RC_EINVAL, "rc_onehot_from_code_blocks: bad code buffer / pitch%s");
+    if (fmt < RC_FMT_U8 || fmt > RC_FMT_BF16 || !onehot || !aligned16(onehot)) return fail(RC_EINVAL, "rc_onehot_from_code_blocks: dense fmt and aligned buffer required%s");
+    if (n_blocks < 1 || n_blocks > 65535 || src_block_stride < 0 || src_block_stride % 16 || dst_block_stride < n)
+        return fail(RC_EINVAL, "rc_onehot_from_code_blocks: 1..65535 blocks, source stride a multiple of 16 bytes, destination stride >= n cubes%s");
+    const int64_t esz = fmt == RC_FMT_U8 ? 1 : fmt == RC_FMT_F32 ? 4 : 2;
+    if (n == 0) return RC_OK;
+    return by_size(cube_size, [&](auto t) {
+        using T = decltype(t);
+        if ((dst_block_stride * T::R * T::C * esz) % 16) return fail(RC_EINVAL, "rc_onehot_from_code_blocks: every block of the output must start 16-byte aligned%s");
+        // the tile kernels only (blocks of a small batch: the front / wide forms pay off from 2^15 cubes per launch, and a caller with
+        // blocks that large loses nothing by launching them one by one)
+        if (n >= ((int64_t)1 << 17) && !(T::SIZE == 2 && fmt != RC_FMT_U8)) return launch_code_to_dense<T, 256>(code, n, code_pitch, sh, onehot, fmt, S(stream), n_blocks, src_block_stride, dst_block_stride);
+        return launch_code_to_dense<T, 64>(code, n, code_pitch, sh, onehot, fmt, S(stream), n_blocks, src_block_stride, dst_block_stride);
+    });
 }
 
 int rc_expand_children_ex(const uint8_t *in, int64_t n, int64_t pitch_in, int cube_size, uint8_t *children, uint8_t *child_solved,

@@ -296,6 +296,26 @@ def onehot_from_code(code, n, cube_size, onehot, variant=0):
     check(lib().rc_onehot_from_code_ex(ptr(code), n, cp, cube_size, ptr(onehot), fmt, stream_ptr(code.device), variant))
 
 
+def onehot_from_code_blocks(code, n, cube_size, onehot, block_stride):
+    """Several equally tiled code buffers -> packed dense blocks in ONE launch (rc_onehot_from_code_blocks).  code: contiguous uint8
+    [n_blocks, tiles, SLOTS, pitch] (n cubes each); block b fills onehot[b * block_stride : b * block_stride + n] (block_stride >= n and
+    every block 16-byte aligned: a multiple of 16 cubes always is).  The 2x2x2 ADI pipeline's one-hot launch."""
+    _size(cube_size)
+    if code.dim() != 4 or not code.is_contiguous():
+        raise RubikHipError("onehot_from_code_blocks: need a contiguous [n_blocks, tiles, SLOTS, pitch] code buffer")
+    cp = _tiled(code[0], N_SLOTS[cube_size], n, "onehot_from_code_blocks")
+    nb = code.shape[0]
+    if code.shape[1] != _tiles_of(n, cp):
+        raise RubikHipError(f"onehot_from_code_blocks: {code.shape[1]} tiles per block, {n} cubes need {_tiles_of(n, cp)}")
+    fmt = _lib.fmt_of(onehot.dtype)
+    R, C = STATE_DIM[cube_size]
+    rows = (nb - 1) * block_stride + n
+    if not onehot.is_cuda or not onehot.is_contiguous() or onehot.dim() != 3 or tuple(onehot.shape[1:]) != (R, C) or onehot.shape[0] < rows or block_stride < n:
+        raise RubikHipError(f"onehot_from_code_blocks: need a contiguous HIP tensor [>= (n_blocks - 1) * block_stride + n, {R}, {C}] and block_stride >= n")
+    _lib.init(code.device)
+    check(lib().rc_onehot_from_code_blocks(ptr(code), n, cp, cube_size, ptr(onehot), fmt, nb, code.stride(0), block_stride, stream_ptr(code.device)))
+
+
 def onehot_from_family(family, n, cube_size, onehot, block_stride, n_depths=1):
     """FAMILY rows of `n_depths` consecutive depths ([n_depths, tiles, NF, pitch]; one depth may drop the leading axis; n walks) -> the
     dense one-hots of all A children and the parent of every depth in ONE launch: depth g, child a fills
@@ -307,6 +327,11 @@ def onehot_from_family(family, n, cube_size, onehot, block_stride, n_depths=1):
     if n_depths != 1 or family.dim() > 3:
         if family.dim() != 4 or family.shape[0] != n_depths or not family.is_contiguous():
             raise RubikHipError(f"onehot_from_family: {n_depths} depths need a contiguous [n_depths, tiles, {nf}, pitch] buffer")
+        if n_depths > 1 and family.shape[1] != _tiles_of(n, pitch):
+            # the library derives the per-depth source stride from n (ceil(n / pitch) tiles): a record with more tiles than that
+            # (e.g. the first n < W walks of a W-walk record) would be read at the wrong offsets from depth 1 on
+            raise RubikHipError(f"onehot_from_family: {family.shape[1]} tiles per depth, but {n} walks at pitch {pitch} are {_tiles_of(n, pitch)}: "
+                                "slice the record to that many tiles (contiguous) first")
     fmt = _lib.fmt_of(onehot.dtype)
     R, C = STATE_DIM[cube_size]
     rows = (n_depths * (A + 1) - 1) * block_stride + n

@@ -17,7 +17,7 @@ int main(void) {
     const int64_t n = 5, pitch = 256;
     uint8_t *st, *act, *done, host[54 * 256], hdone[8], hact[16];
     float *reward, hrew[8];
-    if (rc_version() < 500) return 1;
+    if (rc_version() < 600 || strlen(rc_build_id()) != 16) return 1;      /* the 16 hex digits of the source hash the build embedded */
     /* a caller that skips rc_init gets RC_ENODEV, not a raw launch error */
     if (rc_fill_solved((uint8_t *)host, n, pitch, 3, NULL) != RC_ENODEV || strlen(rc_last_error()) == 0) return 16;
     RC(rc_init(0));

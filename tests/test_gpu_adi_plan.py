@@ -101,7 +101,8 @@ def test_adi_plan_groups_chunks_and_graph(oracle, cs):
             assert (oh.cpu().numpy() == want).all(), what
     # the plan object: geometry, then eager and graph runs over the same static buffers
     plan = AdiPlan(model, cs, 333, 11, T, dense_budget_bytes=4 * A1 * row * 336 + 5)
-    assert plan.group == (4 if cs == 3 else 2) and plan.chunk == 333 and len(plan.chunks) == 1     # 2x2x2 blocks are padded to 512 walks
+    assert plan.group == 4 and plan.chunk == 333 and len(plan.chunks) == 1     # packed blocks for both sizes (round 6: 2x2x2 blocks were padded to 512 walks)
+    assert plan.chunks[0][2]["bs"] == 336 and plan.dense.shape[0] == 4 * A1 * 336
     plan = AdiPlan(model, cs, 2500, 5, T, dense_budget_bytes=A1 * row * 1100)
     assert plan.chunk == 1024 and [c[1] for c in plan.chunks] == [1024, 1024, 452]
     gplan = AdiPlan(model, cs, 777, 9, T, graph=True)
@@ -163,8 +164,60 @@ def test_family_and_targets_depth_groups_match_single_depth_launches(ops, L, ora
         assert float(tv[:3].abs().sum()) == 0 and float(tv[:, 0].abs().sum()) == 0 and float(tv[:, D + 1].abs().sum()) == 0   # nothing outside the view
     with pytest.raises(L.RubikHipError):
         ops.onehot_from_family(bufs["family"], n, 3, many[:100], block_stride=bs, n_depths=D)
+    # a record with MORE tiles per depth than the n walks converted (the first n < W walks of a W-walk record) is refused: the library
+    # derives the per-depth source stride from n, so depths >= 1 would be read from the wrong offsets
+    few = 20000                                                        # 2 of the 3 tiles of the 40000-walk record
+    with pytest.raises(L.RubikHipError, match="tiles per depth"):
+        ops.onehot_from_family(bufs["family"], few, 3, many, block_stride=bs, n_depths=D)
+    sliced = bufs["family"][:, :2].contiguous()
+    ops.onehot_from_family(sliced, few, 3, many, block_stride=bs, n_depths=D)
+    assert (many.view(D, 13, bs, 20, 24)[:, 12, :few].argmax(-1).cpu().numpy().transpose(1, 0, 2) == exp["parent_code"][:few]).all()
     with pytest.raises(L.RubikHipError):
         ops.adi_targets_depths(v[:10], 13 * bs, bs, bufs["child_solved"], v[12 * bs:], 13 * bs, wgt, n, D, 3, tv[3:, 1:], tp[3:, 1:], er[3:, 1:])
+
+
+@pytest.mark.parametrize("cs", [2, 3])
+def test_onehot_from_code_blocks_packs_equally_tiled_buffers(ops, L, oracle, cs):
+    """rc_onehot_from_code_blocks (round 6): the A child-code buffers of several depths of ONE rc_adi_generate call, each [tile][SLOTS][pitch],
+    become packed dense blocks in one launch -- every block against the oracle's child codes, every dense format, one tile and several, pad
+    rows between blocks untouched.  (cube_env.py:143-147 / py333.py:235-246 define the one-hot; the 2x2x2 ADI plan launches this.)"""
+    A, SL, (R, C) = (6, 7, (7, 21)) if cs == 2 else (12, 20, (20, 24))
+    for n, D in ((333, 3), (20001, 2)):
+        pitch, bufs = ops.adi_buffers(n, D, cs, "cuda", parent_code=True, child_code=True)
+        ops.adi_generate(n, D, cs, pitch, "cuda", seed=8, stream_id=2, **bufs)
+        exp = oracle.adi(cs, n, D, seed=8, stream=2, want_children=False, threads=4)
+        tiles = bufs["child_code"].shape[2]
+        bs = -(-n // 16) * 16 + 16                                     # a stride with a whole pad chunk behind every block
+        for dt in (torch.float32, torch.bfloat16, torch.float16, torch.uint8):
+            x = torch.full((D * A * bs + D * bs, R, C), 7, dtype=dt, device="cuda")
+            ops.onehot_from_code_blocks(bufs["child_code"].view(D * A, tiles, SL, pitch), n, cs, x[:D * A * bs], bs)
+            ops.onehot_from_code_blocks(bufs["parent_code"], n, cs, x[D * A * bs:], bs)
+            kids = x[:D * A * bs].view(D, A, bs, R, C)
+            pars = x[D * A * bs:].view(D, bs, R, C)
+            assert float(kids[:, :, n:].float().min()) == 7 and float(pars[:, n:].float().min()) == 7       # pad rows untouched
+            assert float(kids[:, :, :n].float().sum()) == D * A * n * SL and float(pars[:, :n].float().sum()) == D * n * SL
+            for got, want in ((kids[:, :, :n], exp["child_code"].transpose(1, 2, 0, 3)), (pars[:, :n], exp["parent_code"].transpose(1, 0, 2))):
+                g = got.float().cpu().numpy()
+                code = want.astype(np.int64)
+                if cs == 3:
+                    assert (g.argmax(-1) == code).all(), (n, dt)
+                else:                                                  # row = piece = code // 3, column = slot * 3 + code % 3
+                    idx = np.broadcast_to(np.arange(7), code.shape)
+                    assert (np.take_along_axis(g.reshape(*g.shape[:-2], R * C), (code // 3) * C + idx * 3 + code % 3, -1) == 1).all(), (n, dt)
+        one = torch.zeros((n, R, C), dtype=torch.float32, device="cuda")
+        ops.onehot_from_code(bufs["parent_code"][1], n, cs, one)
+        assert torch.equal(x[D * A * bs + bs:D * A * bs + bs + n].float(), one)                             # == the single-buffer entry point
+    with pytest.raises(L.RubikHipError):
+        ops.onehot_from_code_blocks(bufs["parent_code"], n, cs, x[:10], bs)
+    with pytest.raises(L.RubikHipError):
+        ops.onehot_from_code_blocks(bufs["parent_code"], n, cs, x, n - 1)
+    lib, sp, P = L.lib(), L.stream_ptr(torch.device("cuda", torch.cuda.current_device())), lambda t: t.data_ptr()
+    pc = bufs["parent_code"]
+    assert lib.rc_onehot_from_code_blocks(P(pc), n, pitch, cs, P(x), L.FMT_F32, 0, pc.stride(0), bs, sp) != 0          # no blocks
+    assert lib.rc_onehot_from_code_blocks(P(pc), n, pitch, cs, P(x), L.FMT_F32, 2, pc.stride(0) + 8, bs, sp) != 0      # misaligned source stride
+    assert lib.rc_onehot_from_code_blocks(P(pc), n, pitch, cs, P(x), L.FMT_U8, 2, pc.stride(0), n if cs == 2 else n - 1, sp) != 0   # 20001 x 147 B blocks are not 16-byte aligned / stride < n
+    assert lib.rc_onehot_from_code_blocks(P(pc), 0, pitch, cs, P(x), L.FMT_F32, 2, pc.stride(0), bs, sp) == 0          # nothing to do
+    assert L.read_status() == 0
 
 
 def _numpy_legacy(seeds, ks, A):

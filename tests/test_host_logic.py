@@ -110,9 +110,13 @@ def test_abi_exports_every_declared_symbol():
     assert len(declared) >= 15
     for name in declared:
         assert hasattr(L, name), name
-    assert L.rc_version() >= 500 and len(declared) == 36 and {"rc_describe_dispatch", "rc_facade_release", "rc_apply_moves_ws", "rc_encode_ws", "rc_workspace_bytes",
+    assert L.rc_version() >= 600 and len(declared) == 38 and {"rc_build_id", "rc_onehot_from_code_blocks", "rc_describe_dispatch", "rc_facade_release", "rc_apply_moves_ws", "rc_encode_ws", "rc_workspace_bytes",
                                                               "rc_adi_generate_family", "rc_family_layout", "rc_onehot_from_family", "rc_onehot_from_family_depths",
                                                               "rc_adi_targets_depths", "rc_legacy_scramble_actions_ex", "rc_host_alias", "rc_scramble_from", "rc_search_pack"} <= declared
+    # the binary is the tree's sources: the id embedded at build time (rc_build_id) = the hash of rubikhip.hip + rc_device.h + rc_tables.h +
+    # rubikhip.h as they are on disk (a stale library would not even have loaded: _lib.lib() refuses it)
+    from rubiks_cube_solver_amd import _build
+    assert _lib.build_id() == _build.source_hash(_build.HIP_SOURCES) == _build.embedded_id(_lib.LIB_PATH) and len(_lib.build_id()) == 16
     # every rc_* the library exports is declared in the header, and nothing else leaves it
     import subprocess
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
@@ -172,7 +176,7 @@ def test_dispatch_description_and_enodev_without_gpu():
     assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 20, fmt=L.FMT_BF16).startswith("k_code_to_dense_front<Cube3,bf16,F=1,lds> cubes_per_pass=4 xcd grid=262144")
     assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 20, fmt=L.FMT_U8).startswith("k_code_to_dense_front<Cube3,u8,F=2,lds> cubes_per_pass=8 xcd grid=65536")
     assert L.describe(L.OP_CODE_TO_DENSE, 3, 1 << 20, fmt=L.FMT_BF16, variant=20).startswith("k_code_to_dense_front<Cube3,bf16,F=1,lds> cubes_per_pass=4 grid=262144")
-    assert L.describe(L.OP_CODE_TO_DENSE, 2, 1 << 20, fmt=L.FMT_F32).startswith("k_code_to_dense<Cube2,f32,TILE=64> grid=2048 block=256")
+    assert L.describe(L.OP_CODE_TO_DENSE, 2, 1 << 20, fmt=L.FMT_F32).startswith("k_code_to_dense<Cube2,f32,TILE=64> grid=2048 block=640")   # round 6: dense_write_222 on 640 threads
     assert L.describe(L.OP_CODE_TO_DENSE, 2, 1 << 20, fmt=L.FMT_BF16).startswith("k_code_to_dense<Cube2,bf16,TILE=64> grid=16384 block=320")   # the 147-chunk pass writer
     assert L.describe(L.OP_CODE_TO_DENSE, 2, 1 << 20, fmt=L.FMT_U8).startswith("k_code_to_dense<Cube2,u8,TILE=256> grid=4096 block=320")
     # thresholds of the front writer: 2^15 (f32), 2^16 (16-bit), 2^18 (u8); 64-cube tiles below

@@ -459,66 +459,9 @@ __global__ void __launch_bounds__(256) k_code_to_dense_front(const uint8_t *__re
     }
 }
 
-// FRONT form for the 2x2x2 (round 6).  147 elements per cube are not a whole number of 16-byte chunks, but EPT = 16 / sizeof(E) cubes are
-// exactly 147 chunks: a PASS = 4 / 8 / 16 whole cubes = 2352 contiguous bytes, written by 147 lanes with one store each.  A workgroup
-// writes NP consecutive passes of each of its F fronts (NP * 147 lanes busy of a block of 192 / 320 / 640) and ends, like the 3x3x3 front
-// writer: blocks b, b + 8, ... (one XCD) sweep one eighth of the buffer in address order.  The code bytes of a workgroup's passes are
-// 7 slots x (NP * EPT / 4) aligned dwords, fetched by the first lanes with one load each and handed over through LDS; which dword, which
-// byte of it and which code value make each of a lane's EPT elements a 1 is fixed per lane (row = piece, column = slot * 3 + orientation,
-// cube_env.py:143-147), so an element costs one LDS dword read, a shift and a compare.
-template <class T, class E, int F, int NP>
-__global__ void __launch_bounds__(NP == 1 ? 192 : NP == 2 ? 320 : 640) k_code_to_dense_front222(const uint8_t *__restrict__ code, int64_t n, int64_t code_pitch, int shift,
-                                                                                              E *__restrict__ dense, int64_t per_xcd, int64_t per_front) {
-    static_assert(T::SIZE == 2 && T::R * T::C == 147 && (NP == 1 || NP == 2 || NP == 4));
-    constexpr int EPT = 16 / (int)sizeof(E), CPW = NP * EPT, WORDS = CPW / 4;       // cubes per workgroup-front, code dwords per slot
-    __shared__ uint32_t rows[F][T::SLOTS * WORDS];
-    const int tid = threadIdx.x;
-    const int q = tid / 147, t = tid - q * 147;                                      // pass of the workgroup-front, chunk of the pass
-    const int64_t unit0 = per_xcd > 0 ? (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
-#pragma unroll
-    for (int f = 0; f < F; ++f) {
-        const int64_t cube0 = (unit0 + f * per_front) * CPW;
-        if (tid < T::SLOTS * WORDS && (f == 0 || per_front > 0)) {
-            const int r = tid / WORDS, w = tid - r * WORDS;
-            if (cube0 + 4 * w < n) rows[f][tid] = *reinterpret_cast<const uint32_t *>(code + tile_off(cube0 + 4 * w, code_pitch, shift, T::SLOTS) + (int64_t)r * code_pitch);
-        }
-    }
-    uint32_t idx[EPT], sh8[EPT], want[EPT];                                          // LDS dword, bit offset of the byte, the code that makes a 1
-#pragma unroll
-    for (int j = 0; j < EPT; ++j) {
-        const uint32_t g = (uint32_t)t * EPT + j, c = g / 147u, e = g - c * 147u;
-        const uint32_t piece = e / 21u, rem = e - piece * 21u, slot = rem / 3u, ori = rem - slot * 3u;
-        const uint32_t cw = (uint32_t)q * EPT + c;                                   // cube inside the workgroup-front
-        idx[j] = slot * WORDS + (cw >> 2);
-        sh8[j] = 8u * (cw & 3u);
-        want[j] = piece * 3u + ori;
-    }
-    __syncthreads();
-    if (q >= NP) return;
-    const int64_t total = n * 147;
-#pragma unroll
-    for (int f = 0; f < F; ++f) {
-        const int64_t unit = unit0 + f * per_front, first = unit * CPW + (int64_t)q * EPT;     // first cube of this lane's pass
-        if (first >= n || (f > 0 && per_front == 0)) continue;
-        uint32_t w4[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int j = 0; j < EPT; ++j) {
-            const uint32_t one = ((rows[f][idx[j]] >> sh8[j]) & 0xffu) == want[j] ? One<E>::v : 0u;
-            w4[j * (int)sizeof(E) / 4] |= one << (8 * ((j * (int)sizeof(E)) & 3));
-        }
-        const int64_t e0 = first * 147 + (int64_t)t * EPT;
-        if (e0 + EPT <= total) {
-            Pk<4> u;
-            u.d[0] = w4[0]; u.d[1] = w4[1]; u.d[2] = w4[2]; u.d[3] = w4[3];
-            bst<4, RC_DENSE_AUX>(make_srd(dense + unit * CPW * 147), (uint32_t)(q * 147 + t) * 16u, 0, u);
-        } else {                                                                   // ragged end of the last pass
-            for (int j = 0; e0 + j < total; ++j) {
-                const uint32_t bit = (uint32_t)j * (uint32_t)sizeof(E) * 8u;
-                dense[e0 + j] = __builtin_bit_cast(E, (typename UIntOf<sizeof(E)>::type)(w4[bit >> 5] >> (bit & 31u)));
-            }
-        }
-    }
-}
+// (A FRONT form for the 2x2x2 -- 2352-byte passes, 1 / 2 / 4 passes per workgroup-front, 1 / 2 fronts, code dwords through LDS -- was built
+// and measured in round 6 and lost to the tile kernels for every format and size: f32 0.34-0.65 against 0.66, bf16 0.27-0.48 against 0.52,
+// u8 0.17-0.27 against 0.52-0.56 at 1M-4M cubes; profiles/r06_front222.json, EXPERIMENTS.md.  The kernel is in the git history.)
 
 // ---------------------------------------------------------------------------- expand
 struct ExpandArgs {
@@ -1389,7 +1332,7 @@ inline DenseForm dense_form(int64_t n, int variant, bool fused, int fmt) {
     if (forced == 1) return kDense64;
     if (forced == 2) return kDense256;
     if (forced == 3) return wide_ok ? kDenseWide : kDense256;
-    if (forced == 4) return !fused ? kDenseFront : kDense256;            // (2x2x2: k_code_to_dense_front222)
+    if (forced == 4) return wide_ok ? kDenseFront : kDense256;
     // Measured over 2^15 .. 2^22 cubes, two buffers each (profiles/r04_dense_sizes.json, fraction of the 8 TB/s peak):
     //   code -> dense: the front writer from 2^15 (f32: 0.73 against 0.63), 2^16 (16-bit: 0.69 against 0.65), 2^18 (u8: 0.75 against
     //                  0.72) cubes -- 0.83-0.95 / 0.77-0.89 / 0.75-0.82 beyond, on every allocation; 64-cube tiles below
@@ -1516,27 +1459,6 @@ int launch_family_to_dense(const uint8_t *fam, int64_t n, int64_t pitch, int sh,
     return launch_family_e<T, float, 1, false>(fam, n, pitch, sh, static_cast<float *>(onehot), block_stride, dp, st);
 }
 
-template <class T, class E, int F, int NP>
-int launch_front222(const uint8_t *code, int64_t n, int64_t code_pitch, int sh, E *onehot, hipStream_t st, bool linear) {
-    if constexpr (T::SIZE == 2) {
-        constexpr int cpw = NP * (16 / (int)sizeof(E));                              // cubes per workgroup-front
-        const int64_t units = (n + cpw - 1) / cpw;
-        int64_t per_xcd = 0, per_front = 0, blocks = units;
-        if (!linear) {
-            per_front = (units + 8 * F - 1) / (8 * F);
-            per_xcd = per_front * F;
-            blocks = per_front * 8;
-        }
-        RC_GRID(blocks);
-        hipLaunchKernelGGL((k_code_to_dense_front222<T, E, F, NP>), dim3((unsigned)blocks), dim3(NP == 1 ? 192 : NP == 2 ? 320 : 640), 0, st, code, n, code_pitch, sh, onehot,
-                           per_xcd, per_front);
-        RC_HIP(hipGetLastError());
-        return RC_OK;
-    } else {
-        return fail(RC_EINVAL, "the 2x2x2 front writer%s");
-    }
-}
-
 template <class T>
 int launch_code_to_dense_front(const uint8_t *code, int64_t n, int64_t code_pitch, int sh, void *onehot, int fmt, hipStream_t st, int variant) {
     if constexpr (T::SIZE == 3) {
@@ -1546,27 +1468,7 @@ int launch_code_to_dense_front(const uint8_t *code, int64_t n, int64_t code_pitc
         if (fmt == RC_FMT_BF16) return launch_front_shape<T>(code, n, code_pitch, sh, static_cast<Bf16 *>(onehot), st, s);
         return launch_front_shape<T>(code, n, code_pitch, sh, static_cast<float *>(onehot), st, s);
     } else {
-        // 2x2x2 front (k_code_to_dense_front222): `variant` units digit 1 | 2 = fronts per XCD per workgroup; tens digit 2 = one linear
-        // front (as for the 3x3x3), 3 | 4 = 1 | 4 passes per workgroup-front (block 192 | 640) instead of 2 (block 320)
-        const int f = variant % 10 == 2 ? 2 : 1, t = (variant / 10) % 10;
-        const int np = t == 3 ? 1 : t == 4 ? 4 : 2;
-        const bool linear = t == 2;
-        auto go = [&](auto *out) {
-            using E = std::remove_pointer_t<decltype(out)>;
-            if (f == 2) {
-                if (np == 1) return launch_front222<T, E, 2, 1>(code, n, code_pitch, sh, out, st, linear);
-                if (np == 4) return launch_front222<T, E, 2, 4>(code, n, code_pitch, sh, out, st, linear);
-                return launch_front222<T, E, 2, 2>(code, n, code_pitch, sh, out, st, linear);
-            }
-            if (np == 1) return launch_front222<T, E, 1, 1>(code, n, code_pitch, sh, out, st, linear);
-            if (np == 4) return launch_front222<T, E, 1, 4>(code, n, code_pitch, sh, out, st, linear);
-            return launch_front222<T, E, 1, 2>(code, n, code_pitch, sh, out, st, linear);
-        };
-        if (code_pitch % 64) return launch_code_to_dense<T, 64>(code, n, code_pitch, sh, onehot, fmt, st);   // a workgroup-front's cubes must lie in one tile
-        if (fmt == RC_FMT_U8) return go(static_cast<uint8_t *>(onehot));
-        if (fmt == RC_FMT_F16) return go(static_cast<uint16_t *>(onehot));
-        if (fmt == RC_FMT_BF16) return go(static_cast<Bf16 *>(onehot));
-        return go(static_cast<float *>(onehot));
+        return launch_code_to_dense<T, 256>(code, n, code_pitch, sh, onehot, fmt, st);
     }
 }
 

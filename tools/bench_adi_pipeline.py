@@ -4,7 +4,7 @@ with a random-init stand-in of the reference's DeepCube (model.py, hidden [1024,
 393 samples/s on one CPU core with the same net; its own size is 200 cubes x depth 30
 (config/config.yaml:7-8, called once per epoch by train.py:152-155).
 
-    python tools/bench_adi_pipeline.py [walks ...] [--graph] [--reps R]
+    python tools/bench_adi_pipeline.py [walks ...] [--graph] [--reps R] [--depth D] [--cube-size 2|3]
 
 Under `rocprofv3 --kernel-trace` every timed call is bracketed by three k_fill_solved launches on a 1-cube buffer (a kernel the
 pipeline itself never launches), so tools/adi_split.py can cut the trace at the call's boundaries."""
@@ -65,9 +65,10 @@ def main():
     ap.add_argument("--graph", action="store_true")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--depth", type=int, default=30)
+    ap.add_argument("--cube-size", type=int, default=3)
     a = ap.parse_args()
     sizes = tuple((w, a.depth) for w in a.walks) or SIZES
-    print(json.dumps(run(sizes, a.reps, graph=a.graph, markers=True)))
+    print(json.dumps(run(sizes, a.reps, graph=a.graph, markers=True, cube_size=a.cube_size)))
 
 
 if __name__ == "__main__":

@@ -114,3 +114,19 @@ def test_native_rng_is_cpython_randint():
     nat.sync_rngs()
     for g, r in zip(gens, ref):
         assert g.getstate() == r.getstate()
+
+
+def test_tree_driver_thread_count_invariance(tmp_path):
+    """tests/abi/tree_driver.cpp: a plain C++ consumer of include/rubiktree.h (no Python in the process) -- the program
+    tools/sanitize_cpu.sh runs under ASan / UBSan / TSan -- built here with g++ and run plain: 1 thread and 4 threads must leave every
+    root identical (simulations, visit counts, values, solutions, generator states) with per-root generators and with the shared
+    generator consumed in root order (mcts.py:52-154 semantics; random.randint draws at mcts.py:69-70)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "tree_driver")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fopenmp", "-ffp-contract=off", "-Wall", "-Wextra", "-Werror", f"-I{root}/include",
+                           os.path.join(root, "tests", "abi", "tree_driver.cpp"), os.path.join(root, "rubiks-cube-solver_amd", "csrc", "rc_tree.cpp"), "-o", exe])
+    for args in (["96", "40", "4"], ["33", "25", "3"]):
+        out = subprocess.run([exe, *args], capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="4"))
+        assert out.returncode == 0 and out.stdout.startswith("tree_driver ok:") and "identical" in out.stdout, out.stdout + out.stderr

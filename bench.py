@@ -518,10 +518,14 @@ def main():
         if n_devices < 1:
             sys.exit("bench.py needs a GPU (RC_BENCH_DRY=1 --backend gloo rehearses the plumbing without one)")
         if local_rank >= n_devices:
-            if not args.share_gpu:
+            masked = any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+            if args.share_gpu:
+                dev_index = local_rank % n_devices
+            elif masked and n_devices == 1:
+                dev_index = 0      # a launcher that shows every rank ONE card of its own: verified below (distinct PCI bus ids) before a line is printed
+            else:
                 sys.exit(f"rank {rank}: LOCAL_RANK {local_rank} >= {n_devices} visible device(s); one rank per GPU is the contract "
                          "(--share-gpu folds ranks onto the same GPU for a rehearsal)")
-            dev_index = local_rank % n_devices
         torch.cuda.set_device(dev_index)
     if world > 1 and not args.configs:
         args.no_configs = True                                        # rank 0 leaves with the others; N = 1 carries the per-config records
@@ -626,6 +630,11 @@ def main():
                      "GBps": BYTES_PER_STEP * n / (float(x[2]) * 1e-6) / 1e9,
                      "initial_state_sha256_first_cubes": shas[r]["sha"], "sha_cubes": k}
                     for r, x in enumerate(every)]
+        cards = {r["pci_bus_id"] for r in per_rank}
+        if not dry and not args.share_gpu and len(cards) < world:
+            # never an "N-GPU" line from fewer cards: every rank sees the same gathered list and leaves with the same error
+            sys.exit(f"rank {rank}: {world} ranks ran on {len(cards)} distinct device(s) {sorted(cards)}: one rank per GPU is the contract "
+                     "(--share-gpu marks a rehearsal)")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dev_ms, launch_us, launch_max = float(t[0]), float(t[1]), float(t[2]), float(t[4])
         launch_min = min(float(x[3]) for x in every)

@@ -22,7 +22,14 @@ from . import _lib, ops
 from .tables import ACTION_NAMES, get_env_config, get_tables
 
 
-class CubeEnv:
+try:                       # the reference's class is a gym.Env (cube_env.py:12); gym is not a dependency of this package, but where a caller's
+    import gym as _gym     # environment has it, CubeEnv is one too (isinstance checks, gym.make's registry entry: register_gym below)
+    _EnvBase = _gym.Env
+except Exception:          # not installed (or a broken install): a plain class with the same surface
+    _EnvBase = object
+
+
+class CubeEnv(_EnvBase):
     metadata = {"render_modes": ["human", "rgb_array"]}
 
     def __init__(self, device, cube_size=2, compute_device=None):

@@ -654,3 +654,43 @@ def test_cube_env_subclass_survives_deepcopy_and_plan_key():
         assert made == ["torch.float32", "torch.bfloat16"] and len(sink) == 18 and len(env._adi_plans) == 1
     finally:
         type(env)._new_adi_plan = orig
+
+
+def test_a_stale_library_is_refused_and_rebuilt_by_id_not_by_mtime(tmp_path):
+    """rc_build_id (round 6): the binding loads only a library whose embedded source hash equals the hash of the tree's sources, and
+    build() decides by that id, never by modification times.  A copy of the shipped library with ONE hex digit of its id changed (= a
+    binary built from other sources) and the newest mtime of all: refused by _lib.lib() in a fresh process, accepted only with
+    RC_ALLOW_STALE=1 (A/B experiments), and seen as stale by the build's own check."""
+    import shutil
+    import subprocess
+    from rubiks_cube_solver_amd import _build, _lib
+    want = _build.source_hash(_build.HIP_SOURCES)
+    assert want and _build.embedded_id(_lib.LIB_PATH) == want
+    fake = str(tmp_path / "librubikhip.so")
+    data = bytearray(open(_lib.LIB_PATH, "rb").read())
+    i = data.find(_build.MARKER) + len(_build.MARKER)
+    data[i] = ord("0") if data[i] != ord("0") else ord("1")
+    open(fake, "wb").write(bytes(data))
+    os.utime(fake, None)                                               # newer than every source: an mtime rule would call it current
+    assert _build.embedded_id(fake) != want and os.path.getmtime(fake) >= max(os.path.getmtime(p) for p in _build.HIP_SOURCES)
+    code = "from rubiks_cube_solver_amd import _lib; L = _lib.lib(); print('loaded', _lib.build_id())"
+    env = dict(os.environ, RUBIKHIP_LIB=fake)
+    env.pop("RC_ALLOW_STALE", None)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "is stale" in out.stderr and "loaded" not in out.stdout, out.stderr[-2000:]
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(env, RC_ALLOW_STALE="1"))
+    assert out.returncode == 0 and "loaded " + _build.embedded_id(fake) in out.stdout, out.stderr[-2000:]
+    # the tree library goes through the same check
+    from rubiks_cube_solver_amd import _tree
+    tfake = str(tmp_path / "librubiktree.so")
+    tdata = bytearray(open(_tree.LIB_PATH, "rb").read())
+    j = tdata.find(_build.MARKER) + len(_build.MARKER)
+    tdata[j] = ord("0") if tdata[j] != ord("0") else ord("1")
+    open(tfake, "wb").write(bytes(tdata))
+    out = subprocess.run([sys.executable, "-c", "from rubiks_cube_solver_amd import _tree; _tree.tree_lib()"], capture_output=True, text=True, timeout=300,
+                         cwd=ROOT, env=dict(os.environ, RUBIKTREE_LIB=tfake))
+    assert out.returncode != 0 and "is stale" in out.stderr, out.stderr[-2000:]
+    # a library without any id (built by hand without -DRC_SRC_HASH, or one that predates round 6) is stale too
+    plain = str(tmp_path / "no_id.so")
+    open(plain, "wb").write(b"\x7fELF" + b"\0" * 64)
+    assert _build.embedded_id(plain) is None and _build.embedded_id(str(tmp_path / "missing.so")) is None

@@ -591,6 +591,7 @@ def main():
         for _ in range(args.warmup):
             step()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sync_all()                                                       # untimed: the first barrier of a process group builds RCCL's communicator (seconds)
         sync_all()
         t0 = time.perf_counter()
         e0.record()

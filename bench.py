@@ -279,7 +279,19 @@ def other_configs(torch, ops, _lib, dev, acts):
     t = timed(lambda: ops.onehot_from_code(code2, m, 2, oh2), 10, 2)
     rec("2x2x2 1M code->dense f32", "2x2x2 batch 1M, compact code -> dense f32 one-hot [N,7,21] (rc_onehot_from_code)", D(_lib.OP_CODE_TO_DENSE, 2, m, fmt=_lib.FMT_F32), m, "cubes",
         7 + 147 * 4, t)
-    del s2, code2, oh2
+    del code2, oh2
+    # the 2x2x2 ADI plan's one-hot launch (round 6): 12 equally tiled child-code buffers (2 depths x 6 children) of 20000 walks -> packed
+    # blocks of ceil16(walks) rows in ONE launch (rc_onehot_from_code_blocks: the tile kernel with blockIdx.y = block)
+    wn2, nb2 = 20_000, 12
+    pt2, ab2 = ops.adi_buffers(wn2, 2, 2, dev, child_code=True)
+    ops.adi_generate(wn2, 2, 2, pt2, dev, seed=2024, **ab2)
+    bs2 = -(-wn2 // 16) * 16
+    blk2 = torch.zeros((nb2 * bs2, 7, 21), dtype=torch.float32, device=dev)
+    cc2 = ab2["child_code"].view(nb2, -1, 7, pt2)
+    t = timed(lambda: ops.onehot_from_code_blocks(cc2, wn2, 2, blk2, bs2), 20, 3)
+    rec("2x2x2 ADI blocks f32 20000x12", f"2x2x2 ADI child codes -> packed dense f32 blocks: {nb2} code buffers of {wn2} walks in one launch (rc_onehot_from_code_blocks)",
+        D(_lib.OP_CODE_TO_DENSE, 2, wn2, fmt=_lib.FMT_F32) + f" x {nb2} blocks (grid.y)", wn2 * nb2, "cubes", 7 + 147 * 4, t)
+    del s2, ab2, blk2, cc2
     # config 3: ADI data generation
     W, DEPTH = 100_000, 30
     pt, ab = ops.adi_buffers(W, DEPTH, CUBE, dev, parents=True, children=True)

@@ -170,7 +170,7 @@ def test_bench_json_line(tmp_path):
     for name in ("cfg2 1M step+reward", "4M step in place", "4M step+reward", "4M step+reward+code", "16M step (HBM only)",
                  "1M step+dense f32", "1M step+dense bf16", "1M code->dense f32", "1M code->dense bf16", "1M expansion",
                  "cfg3 ADI 100k x 30", "ADI 100k x 30 codes", "ADI 100k x 30 family", "1M code->dense f16", "1M code->dense u8", "1M step+dense u8",
-                 "2x2x2 1M expansion", "2x2x2 1M code->dense f32", "ADI dense blocks f32 43008x1", "ADI dense blocks f32 20000x2", "ADI dense blocks bf16 43008x2"):
+                 "2x2x2 1M expansion", "2x2x2 1M code->dense f32", "2x2x2 ADI blocks f32 20000x12", "ADI dense blocks f32 43008x1", "ADI dense blocks f32 20000x2", "ADI dense blocks bf16 43008x2"):
         x = pc[name]
         assert x["kernel"].startswith("k_") and abs(x["frac"] - x["bytes"] / (x["launch_us"] * 1e-6) / 8e12) < 2e-3, name
     assert len(r["per_config"]) == len(recs)

@@ -36,6 +36,12 @@ Fixtures written (all small, np.savez_compressed):
   mcts_333.npz     G8  the reference's MCTS (mcts.py) driven by a deterministic stub model and a
                    seeded `random`: simulations needed, returned action lists, root statistics;
                    plus reset(seed, 1000) end states for seeds 0..19 (test.py:166,279 style)
+  env222_via_reference.npz G13 the reference's OWN CubeEnv and MCTS run with cube_size = 2, the six names of the file it imports but
+                   does not ship (assets/py222.py, cube_env.py:8) supplied by tests/golden/py222_standin.py (the oracle's restated
+                   tables): reset(seed, k), 300 random walks step by step, state_to_sim_state round trips, get_random_samples /
+                   get_target_value with a linear stub model, MCTS searches.  Pins every 2x2x2 LINE of cube_env.py / mcts.py by
+                   execution (RNG handling, reward / done, the transposed one-hot, the inversion, the target rule, action_dim 6);
+                   the CONTENT of the authors' py222 tables stays unpinned (the stand-in is the build's restatement)
 """
 import hashlib
 import os
@@ -48,7 +54,11 @@ import numpy as np
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = HERE          # --out DIR / --check write somewhere else; the committed fixtures live in HERE
-FIXTURES = ("tables", "walks", "reset", "adi", "expand", "encode", "mcts", "mcts_guided", "rollout", "adi_deepcube", "replay")
+FIXTURES = ("tables", "walks", "reset", "adi", "expand", "encode", "mcts", "mcts_guided", "rollout", "adi_deepcube", "replay", "env222")
+
+
+def fixture_file(group):
+    return "env222_via_reference.npz" if group == "env222" else f"{group}_333.npz"
 
 
 def out_path(name):
@@ -105,7 +115,7 @@ def generate(groups):
     env = cube_env.CubeEnv(dev, cube_size=3)
     assert env.action_to_sim_action[3] == names
     assert [py333.moveInds[n] for n in names] == list(range(12))
-    late = {"mcts", "rollout", "adi_deepcube", "replay", "mcts_guided"}
+    late = {"mcts", "rollout", "adi_deepcube", "replay", "mcts_guided", "env222"}
     if not groups or groups - late:
         base_fixtures(torch, cube_env, py333, env, dev, A, names)
     if want("mcts"):
@@ -118,6 +128,8 @@ def generate(groups):
         golden_replay(torch, env)
     if want("mcts_guided"):
         golden_mcts_guided(torch, cube_env, env)
+    if want("env222"):
+        golden_env222(torch, cube_env)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")
@@ -550,6 +562,125 @@ def golden_mcts(torch, cube_env, env):
     print("mcts:", list(zip(cases, sims)))
 
 
+def cols_222(onehot):
+    """Column index of the single 1.0 in each of the 7 cubelet rows of the 2x2x2 one-hot (cube_env.py:143-147: row = cubelet,
+    column = position * 3 + orientation)."""
+    oh = np.asarray(onehot)
+    assert oh.shape == (7, 21) and oh.dtype == np.float64 and (oh.sum(1) == 1).all() and set(np.unique(oh)) <= {0.0, 1.0}
+    return np.argmax(oh, 1).astype(np.uint8)
+
+
+def golden_env222(torch, cube_env):
+    """G13: the reference's own CubeEnv / MCTS with cube_size = 2.  cube_env.py binds the six py222 names at import time (to the
+    harness stub's None); here they are re-bound, in the imported module's namespace, to tests/golden/py222_standin.py."""
+    import random
+
+    import mcts as ref_mcts
+    import py222_standin as standin
+
+    for name in ("initState", "getOP", "doMove", "isSolved", "getStickers", "printCube"):
+        setattr(cube_env, name, getattr(standin, name))
+    dev = torch.device("cpu")
+    env = cube_env.CubeEnv(dev, cube_size=2)
+    assert env.state_dim == [7, 21] and env.action_dim == 6 and env.action_to_sim_action[2] == ["U", "U'", "F", "F'", "R", "R'"]
+    out = {"action_names": np.array(env.action_to_sim_action[2]), "solved_stickers": np.asarray(env.sim_cube, np.uint8), "solved_cols": cols_222(env.cube),
+           "state_dtype": np.array(str(env.cube.dtype))}
+    # reset(seed, k): the legacy global generator is saved, seeded, used for randint(6, size=k) and restored (cube_env.py:62-68)
+    seeds, ks = np.arange(0, 100, 10), np.arange(1, 15)
+    r_st, r_cols = np.zeros((len(seeds), len(ks), 24), np.uint8), np.zeros((len(seeds), len(ks), 7), np.uint8)
+    np.random.seed(424242)
+    before = np.random.get_state()[1].copy()
+    for i, sd in enumerate(seeds):
+        for j, k in enumerate(ks):
+            state = env.reset(seed=int(sd), scramble_count=int(k))
+            r_st[i, j], r_cols[i, j] = env.sim_cube, cols_222(state)
+    assert (np.random.get_state()[1] == before).all()
+    out.update(reset_seeds=seeds, reset_ks=ks, reset_stickers=r_st, reset_cols=r_cols)
+    # 300 random walks of 14 moves, step by step; every 5th state through state_to_sim_state (cube_env.py:154-175, getStickers)
+    W, D = 300, 14
+    acts = np.random.default_rng(222).integers(0, 6, (W, D), dtype=np.uint8)
+    w_st, w_cols = np.zeros((W, D, 24), np.uint8), np.zeros((W, D, 7), np.uint8)
+    w_done, w_rew, rt = np.zeros((W, D), np.uint8), np.zeros((W, D), np.float64), np.zeros((W, D // 5 + 1, 24), np.uint8)
+    for w in range(W):
+        env.init_state()
+        for d in range(D):
+            state, reward, done, info = env.step(int(acts[w, d]))
+            assert isinstance(reward, float) and isinstance(done, bool) and info == {} and state is env.cube
+            w_st[w, d], w_cols[w, d], w_done[w, d], w_rew[w, d] = env.sim_cube, cols_222(state), done, reward
+            if d % 5 == 0:
+                rt[w, d // 5] = env.state_to_sim_state(env.cube)
+    out.update(walk_actions=acts, walk_stickers=w_st, walk_cols=w_cols, walk_done=w_done, walk_reward=w_rew, roundtrip_stickers=rt)
+    # get_random_samples / get_target_value with a deterministic linear stub (value = <one-hot, w> + b), incl. solved-child breaks at depth 1
+    rng = np.random.default_rng(2222)
+    w_lin, b_lin = torch.tensor((rng.standard_normal(147) * 0.3).astype(np.float32)), torch.tensor(np.float32(0.125))
+
+    class StubModel(torch.nn.Module):
+        def forward(self, x):
+            if x.dim() == 2:
+                x = x.unsqueeze(0)
+            return (x.reshape(x.shape[0], -1) @ w_lin + b_lin).unsqueeze(-1), torch.zeros(x.shape[0], 6)
+
+    n_cubes, depth, temperature, seed = 48, 10, 0.7, 777
+    buf = []
+    np.random.seed(seed)
+    env.get_random_samples(buf, StubModel(), depth, n_cubes, temperature)
+    np.random.seed(seed)
+    adi_actions = np.stack([np.random.randint(6, size=depth) for _ in range(n_cubes)]).astype(np.uint8)   # the draws the call made (cube_env.py:189)
+    shape = (n_cubes, depth)
+    assert len(buf) == n_cubes * depth and list(buf[0].keys()) == ["state", "target_value", "target_policy", "scramble_count", "error"]
+    out.update(adi_w=w_lin.numpy(), adi_b=b_lin.numpy(), adi_seed=np.int64(seed), adi_temperature=np.float64(temperature), adi_actions=adi_actions,
+               adi_cols=np.stack([cols_222(b["state"]) for b in buf]).reshape(*shape, 7),
+               adi_target_value=np.array([b["target_value"] for b in buf], np.float64).reshape(shape),
+               adi_target_policy=np.array([b["target_policy"] for b in buf], np.int64).reshape(shape),
+               adi_scramble_count=np.array([b["scramble_count"] for b in buf], np.int64).reshape(shape),
+               adi_error=np.array([b["error"] for b in buf], np.float64).reshape(shape),
+               adi_final_stickers=np.asarray(env.sim_cube, np.uint8))
+    import utils as ref_utils                                          # the reference's ReplayBuffer over those records: the 5-tuple's dtypes
+    rb = ref_utils.ReplayBuffer(10_000, 5_000)
+    for b in buf:
+        rb.append(b)
+    rb.get_prioritized_sample()
+    out["adi_item_dtypes"] = np.array([str(t.dtype) for t in rb[0]])
+    # the reference's MCTS on the 2x2x2 (action_dim 6 from cfg['test']['cube_size'], mcts.py:33-34)
+    wv = (rng.standard_normal(147) * 0.05).astype(np.float32)
+    wp = (rng.standard_normal((147, 6)) * 0.3).astype(np.float32)
+
+    class Stub:
+        def predict(self, x):
+            f = np.asarray(x, dtype=np.float32).reshape(-1)
+            logits = f @ wp
+            e = np.exp(logits - logits.max())
+            return np.array([f @ wv], np.float32), (e / e.sum()).astype(np.float32)
+
+    cfg = {"mcts": {"virtual_loss_const": 150, "cpuct": 1.0, "value_min": -10.0, "numMCTSSim": 50}, "test": {"cube_size": 2}}
+    cases = [(s, k) for k in (1, 2, 3, 4, 5) for s in range(6)]
+    sims, sol, root_visits, root_values = [], [], [], []
+    for sd, k in cases:
+        state = env.reset(seed=sd, scramble_count=k)
+        random.seed(2000 + 17 * sd + k)
+        tree = ref_mcts.MCTS(Stub(), cfg)
+        found, used = None, 0
+        for i in range(60):
+            used = i + 1
+            found = tree.train(state, env)
+            if found is not None:
+                break
+        sims.append(used)
+        a = np.full(16, 255, np.uint8)
+        if found is not None:
+            a[:len(found)] = found
+        sol.append(a)
+        root = tree.children_and_data[np.array2string(state)]
+        root_visits.append(np.array(root[tree.n_of_v_i], np.int64))
+        root_values.append(np.array([float(np.asarray(v).reshape(-1)[0]) for v in root[tree.s_i]], np.float64))
+    out.update(mcts_wv=wv, mcts_wp=wp, mcts_seeds=np.array([c[0] for c in cases]), mcts_ks=np.array([c[1] for c in cases]),
+               mcts_random_seed=np.array([2000 + 17 * s_ + k for s_, k in cases]), mcts_sims=np.array(sims), mcts_solution=np.stack(sol),
+               mcts_root_visits=np.stack(root_visits), mcts_root_values=np.stack(root_values))
+    np.savez_compressed(out_path("env222_via_reference.npz"), **out)
+    print("env222: walks solved", int(w_done.sum()), "adi solved-child samples", int((out["adi_target_value"] == 1.0).sum()),
+          "mcts sims", sims)
+
+
 def compare(dir_a, dir_b, names):
     """Array-by-array comparison (keys, dtype, shape, values) of the named fixtures in two directories."""
     bad = 0
@@ -592,7 +723,7 @@ def main():
             which = set(args.groups) or set(FIXTURES)
             if which & base:
                 which |= base                                      # G1-G7 are regenerated together
-            names = [f"{g}_333.npz" for g in FIXTURES if g in which]
+            names = [fixture_file(g) for g in FIXTURES if g in which]
             bad = compare(tmp, HERE, names)
         print(f"{len(names) - bad} of {len(names)} fixtures IDENTICAL to the committed ones")
         sys.exit(1 if bad else 0)

@@ -11,6 +11,8 @@ numpy.int, a stub `gym`, a stub `assets.py222`) and hands them the product class
       test.trial(model, env, cfg, k, seed, mask, mcts_)  test.py:103-158  the masked loop (G9) and the MCTS loop (G8)
   (c) utils.ReplayBuffer as the sink of env.get_random_samples, then its prioritised draws, __getitem__ and a DataLoader
       (utils.py:203-270, 296-303)                       vs replay_333.npz (G11)
+  (d) the same MCTS and ReplayBuffer with cube_size = 2   vs env222_via_reference.npz (G13: the reference's own CubeEnv(cube_size=2)
+      over the stand-in py222)
 
 There is no GPU here, so the class is tests/fake_backend.HostLogicCubeEnv: the product's CubeEnv with its four one-launch device
 hooks (and the device plan behind get_random_samples) answered by the CPU oracle.  Everything a caller can observe of the HOST side
@@ -277,6 +279,64 @@ def main():
         tv_ok &= type(tv) is float and type(tp) is int and type(er) is float
         tv_ok &= abs(tv - float(a5["target_value"][0, d])) == 0 and tp == int(a5["target_policy"][0, d]) and abs(er - float(a5["error"][0, d])) == 0
     checks["CubeEnv.get_target_value G5"] = bool(tv_ok)
+
+    # ------------------------------------------------------------------ (d) 2x2x2: the reference's MCTS (action_dim 6) and ReplayBuffer
+    # against the product class with cube_size = 2, vs G13 (what the reference's OWN CubeEnv(cube_size=2) computed over the stand-in py222)
+    q = golden("env222_via_reference")
+    env2 = HostLogicCubeEnv(dev, cube_size=2)
+    cfg2 = {"mcts": dict(CFG["mcts"]), "test": {"cube_size": 2, "max_timesteps": 12}}
+    wv2, wp2 = q["mcts_wv"], q["mcts_wp"]
+
+    class Stub2:
+        def predict(self, x):
+            f = np.asarray(x, dtype=np.float32).reshape(-1)
+            logits = f @ wp2
+            e = np.exp(logits - logits.max())
+            return np.array([f @ wv2], np.float32), (e / e.sum()).astype(np.float32)
+
+    ok = {"sims": True, "solution": True, "root_visits": True, "root_values": True}
+    for i, (seed, k) in enumerate(zip(q["mcts_seeds"], q["mcts_ks"])):
+        state = env2.reset(seed=int(seed), scramble_count=int(k))
+        random.seed(int(q["mcts_random_seed"][i]))
+        tree = ref_mcts.MCTS(Stub2(), cfg2)
+        found, used = None, 0
+        for s_ in range(60):
+            used = s_ + 1
+            found = tree.train(state, env2)
+            if found is not None:
+                break
+        sol = np.full(16, 255, np.uint8)
+        if found is not None:
+            sol[:len(found)] = found
+        root = tree.children_and_data[np.array2string(state)]
+        ok["sims"] &= used == int(q["mcts_sims"][i])
+        ok["solution"] &= bool((sol == q["mcts_solution"][i]).all())
+        ok["root_visits"] &= bool((np.array(root[tree.n_of_v_i], np.int64) == q["mcts_root_visits"][i]).all())
+        ok["root_values"] &= bool((np.array([float(np.asarray(v).reshape(-1)[0]) for v in root[tree.s_i]], np.float64) == q["mcts_root_values"][i]).all())
+    for k_, v in ok.items():
+        checks[f"2x2x2 mcts.MCTS.train G13 {k_}"] = bool(v)
+    w2, b2 = torch.tensor(q["adi_w"]), torch.tensor(q["adi_b"])
+
+    class StubModel2(torch.nn.Module):
+        def forward(self, x):
+            if x.dim() == 2:
+                x = x.unsqueeze(0)
+            return (x.reshape(x.shape[0], -1) @ w2 + b2).unsqueeze(-1), torch.zeros(x.shape[0], 6)
+
+    rb2 = ref_utils.ReplayBuffer(10_000, 5_000)
+    np.random.seed(int(q["adi_seed"]))
+    n2, d2 = q["adi_actions"].shape
+    env2.get_random_samples(rb2, StubModel2(), d2, n2, float(q["adi_temperature"]))
+    cols2 = lambda oh: np.argmax(np.asarray(oh), 1).astype(np.uint8)
+    checks["2x2x2 ReplayBuffer records G13"] = (
+        len(rb2.memory) == n2 * d2 and rb2.memory[0]["state"].dtype == np.float64 and rb2.memory[0]["state"].shape == (7, 21)
+        and bool((np.stack([cols2(m["state"]) for m in rb2.memory]).reshape(n2, d2, 7) == q["adi_cols"]).all())
+        and bool((np.array([m["target_value"] for m in rb2.memory]).reshape(n2, d2) == q["adi_target_value"]).all())
+        and bool((np.array([m["target_policy"] for m in rb2.memory]).reshape(n2, d2) == q["adi_target_policy"]).all())
+        and bool((np.array(rb2.error_memory).reshape(n2, d2) == q["adi_error"]).all()))
+    rb2.get_prioritized_sample()
+    it = rb2[0]
+    checks["2x2x2 ReplayBuffer __getitem__ dtypes"] = [str(t.dtype) for t in it] == list(q["adi_item_dtypes"])
 
     failed = [k for k, v in checks.items() if not v]
     print(json.dumps({"checks": checks, "failed": failed, "reference_modules": ["mcts", "model", "test", "train", "utils"], "env_class": type(env).__mro__[1].__module__}))

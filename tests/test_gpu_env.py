@@ -1060,3 +1060,157 @@ def test_adi_samples_feeds_the_net_in_its_own_dtype(mod):
     assert (a["target_policy"] == b["target_policy"]).float().mean() > 0.9          # near ties may fall differently after bf16 rounding
     c = adi_samples(hi, 3, 500, 4, 0.5, device="cuda", seed=11, dense_dtype=torch.float32)
     assert torch.equal(c["state_code"], b["state_code"][:500, :4])
+
+
+# ------------------------------------------------------------------------------ G13: the reference's own 2x2x2 branches
+def _stub_222(g, device="cpu"):
+    w, b = torch.tensor(g["adi_w"], device=device), torch.tensor(g["adi_b"], device=device)
+
+    class StubModel(torch.nn.Module):
+        def forward(self, x):
+            if x.dim() == 2:
+                x = x.unsqueeze(0)
+            return (x.reshape(x.shape[0], -1).float() @ w + b).unsqueeze(-1), torch.zeros(x.shape[0], 6, device=x.device)
+    return StubModel()
+
+
+def test_facade_222_matches_the_references_own_222_branches(mod, golden):
+    """G13 = the REFERENCE's CubeEnv run with cube_size = 2 (stand-in py222 under it).  The product facade on the GPU: every reset(seed, k),
+    walks step by step (stickers, the transposed float64 one-hot of cube_env.py:143-147, reward, done), state_to_sim_state
+    (cube_env.py:154-175), get_target_value (cube_env.py:196-252; the model is called as the reference calls it: 1e-6)."""
+    g = golden("env222_via_reference")
+    env = mod.make_env(torch.device("cpu"), 2)
+    assert (env.sim_cube == g["solved_stickers"]).all() and (np.argmax(env.cube, 1) == g["solved_cols"]).all() and str(env.cube.dtype) == str(g["state_dtype"])
+    np.random.seed(5)
+    before = np.random.get_state()[1].copy()
+    for i, sd in enumerate(g["reset_seeds"]):
+        for j, k in enumerate(g["reset_ks"]):
+            s = env.reset(seed=int(sd), scramble_count=int(k))
+            assert s.dtype == np.float64 and s.shape == (7, 21) and (np.argmax(s, 1) == g["reset_cols"][i, j]).all() and (s.sum(1) == 1).all()
+            assert (env.sim_cube == g["reset_stickers"][i, j]).all()
+    assert (np.random.get_state()[1] == before).all()
+    for w in range(0, 300, 6):
+        env.init_state()
+        for d in range(14):
+            s, r, dn, info = env.step(int(g["walk_actions"][w, d]))
+            assert (env.sim_cube == g["walk_stickers"][w, d]).all() and (np.argmax(s, 1) == g["walk_cols"][w, d]).all() and (s.sum(1) == 1).all()
+            assert isinstance(r, float) and isinstance(dn, bool) and (r, dn) == (g["walk_reward"][w, d], bool(g["walk_done"][w, d])) and info == {}
+            if d % 5 == 0:
+                assert (env.state_to_sim_state(env.cube) == g["roundtrip_stickers"][w, d // 5]).all()
+    model, T = _stub_222(g), float(g["adi_temperature"])
+    for c in (0, 7, 31):
+        env.init_state()
+        for d in range(g["adi_actions"].shape[1]):
+            env.step(int(g["adi_actions"][c, d]))
+            tv, tp, err = env.get_target_value(model, d + 1, T)
+            assert isinstance(tv, float) and isinstance(tp, int) and tp == g["adi_target_policy"][c, d]
+            assert tv == pytest.approx(g["adi_target_value"][c, d], abs=1e-6) and err == pytest.approx(g["adi_error"][c, d], abs=1e-6)
+
+
+def test_batched_222_walks_and_adi_match_the_references_own_222_branches(mod, oracle, golden):
+    """The batched 2x2x2 kernels against G13: 300 walks stepped together (rc_apply_moves with the fused dense float32 one-hot [N, 7, 21],
+    reward, done), get_random_samples through the facade (dict records, legacy-RNG draws) and adi_samples with replayed moves (AdiPlan's
+    packed blocks, rc_onehot_from_code_blocks): integer outputs exact, value-net floats within 1e-5, policy equal except on a top-2 tie."""
+    from rubiks_cube_solver_amd import _lib, ops
+    from rubiks_cube_solver_amd.adi import adi_samples
+    g = golden("env222_via_reference")
+    W, D = g["walk_actions"].shape
+    st = ops.alloc_states(W, 2, "cuda")
+    ops.fill_solved(st, W, 2)
+    oh = torch.empty((W, 7, 21), dtype=torch.float32, device="cuda")
+    rew = torch.empty(W, dtype=torch.float32, device="cuda")
+    done = torch.empty(W, dtype=torch.uint8, device="cuda")
+    for d in range(D):
+        ops.apply_moves(st, st, torch.from_numpy(g["walk_actions"][:, d].copy()).cuda(), W, 2, rew, done, oh, _lib.FMT_F32)
+        assert (ops.to_aos(st, W).cpu().numpy() == g["walk_stickers"][:, d]).all()
+        assert (oh.argmax(-1).cpu().numpy() == g["walk_cols"][:, d]).all() and float(oh.sum()) == 7 * W
+        assert (done.cpu().numpy() == g["walk_done"][:, d]).all() and (rew.cpu().numpy().astype(np.float64) == g["walk_reward"][:, d]).all()
+    n, depth = g["adi_actions"].shape
+    T = float(g["adi_temperature"])
+    # child values of the stub on the host (float64) for the tie rule
+    out = oracle.adi(2, n, depth, actions_in=g["adi_actions"], want_children=False)
+    wv = g["adi_w"].reshape(7, 21).astype(np.float64)
+    code = out["child_code"].astype(np.int64)
+    v = np.sort(wv[code // 3, np.arange(7) * 3 + code % 3].sum(-1), -1)
+    tie = (v[..., -1] - v[..., -2] < 1e-5) & ~out["child_solved"].any(-1)
+    # (a) the drop-in call: env.get_random_samples with a list sink
+    env = mod.make_env(torch.device("cpu"), 2)
+    buf = []
+    np.random.seed(int(g["adi_seed"]))
+    env.get_random_samples(buf, _stub_222(g), depth, n, T)
+    assert len(buf) == n * depth and (env.sim_cube == g["adi_final_stickers"]).all()
+    for i, smp in enumerate(buf):
+        c, d = divmod(i, depth)
+        assert list(smp) == ["state", "target_value", "target_policy", "scramble_count", "error"] and smp["state"].dtype == np.float64
+        assert (np.argmax(smp["state"], 1) == g["adi_cols"][c, d]).all() and (smp["state"].sum(1) == 1).all() and smp["scramble_count"] == d + 1
+        assert smp["target_value"] == pytest.approx(g["adi_target_value"][c, d], abs=1e-5) and smp["error"] == pytest.approx(g["adi_error"][c, d], abs=1e-5)
+        assert smp["target_policy"] == g["adi_target_policy"][c, d] or tie[c, d], (c, d)
+    assert all(b["target_value"] == 1.0 for b in buf[::depth])
+    # (b) adi_samples with the model on the GPU and the same moves replayed
+    res = adi_samples(_stub_222(g, "cuda"), 2, n, depth, T, device="cuda", actions=g["adi_actions"], want_state_dense=True)
+    assert (res["state"].argmax(-1).cpu().numpy() == g["adi_cols"]).all() and int(res["state"].sum()) == n * depth * 7
+    assert np.allclose(res["target_value"].cpu().numpy(), g["adi_target_value"], rtol=0, atol=1e-5)
+    assert np.allclose(res["error"].cpu().numpy(), g["adi_error"], rtol=0, atol=1e-5)
+    got = res["target_policy"].cpu().numpy()
+    assert ((got == g["adi_target_policy"]) | tie).all() and (got == g["adi_target_policy"]).mean() > 0.99
+    assert (res["target_value"].cpu().numpy()[g["adi_target_value"] == 1.0] == 1.0).all()
+
+
+def test_mcts_222_matches_the_references_own_mcts(mod, golden):
+    """G13: the reference's MCTS (mcts.py, action_dim 6) over ITS OWN CubeEnv(cube_size=2) vs mcts_batched.MCTS over the product facade:
+    simulations used, action lists, root visit counts and values for 30 searches (k = 1..5)."""
+    import random
+
+    from rubiks_cube_solver_amd.mcts_batched import MCTS
+    g = golden("env222_via_reference")
+    wv, wp = g["mcts_wv"], g["mcts_wp"]
+
+    class Stub:
+        def predict(self, x):
+            f = np.asarray(x, dtype=np.float32).reshape(-1)
+            logits = f @ wp
+            e = np.exp(logits - logits.max())
+            return np.array([f @ wv], np.float32), (e / e.sum()).astype(np.float32)
+
+    cfg = {"mcts": {"virtual_loss_const": 150, "cpuct": 1.0, "value_min": -10.0, "numMCTSSim": 50}, "test": {"cube_size": 2}}
+    env = mod.make_env(torch.device("cpu"), 2)
+    for i, (seed, k) in enumerate(zip(g["mcts_seeds"], g["mcts_ks"])):
+        state = env.reset(seed=int(seed), scramble_count=int(k))
+        random.seed(int(g["mcts_random_seed"][i]))
+        tree, found, used = MCTS(Stub(), cfg), None, 0
+        for s in range(60):
+            used = s + 1
+            found = tree.train(state, env)
+            if found is not None:
+                break
+        assert used == int(g["mcts_sims"][i]), (i, used, int(g["mcts_sims"][i]))
+        assert (found or []) == [int(a) for a in g["mcts_solution"][i] if a != 255]
+        root = tree.children_and_data[MCTS.key_of(env)]
+        assert root.visits == g["mcts_root_visits"][i].tolist()
+        assert np.allclose(root.value, g["mcts_root_values"][i], rtol=0, atol=1e-6)
+
+
+def test_py222_names_on_the_device_match_the_standin(mod, golden, capsys):
+    """rubiks_cube_solver_amd.py222: the six names of the reference's missing assets/py222.py (cube_env.py:8) on the device, against the
+    harness stand-in that produced G13 (tests/golden/py222_standin.py) on random walks, and against G13's walk states."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import py222_standin as ref
+    from rubiks_cube_solver_amd import py222 as P
+    assert sorted(P.__all__) == sorted(["initState", "getOP", "doMove", "isSolved", "getStickers", "printCube"])
+    g = golden("env222_via_reference")
+    s, t = P.initState(), ref.initState()
+    assert s.dtype == np.int64 and (s == t).all() and P.isSolved(s) is True and (P.getOP(s) == ref.getOP(t)).all()
+    names = ["U", "U'", "F", "F'", "R", "R'"]
+    for d in range(14):
+        mv = names[int(g["walk_actions"][11, d])]
+        s2, t = P.doMove(s, mv), ref.doMove(t, mv)
+        assert s2 is not s and (s2 == t).all() and (s2 == g["walk_stickers"][11, d]).all()
+        s = s2
+        op = P.getOP(s)
+        assert op.shape == (7, 2) and (op == ref.getOP(t)).all() and P.isSolved(s) == ref.isSolved(t) == bool(g["walk_done"][11, d])
+        assert (P.getStickers(op) == s).all() and (ref.getStickers(op) == s).all()
+    with pytest.raises(KeyError):
+        P.doMove(s, "D")                                             # the 2x2x2 model has no D / B / L turns (cube_env.py:25)
+    P.printCube(s)
+    assert len(capsys.readouterr().out.splitlines()) == 6

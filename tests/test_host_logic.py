@@ -600,7 +600,7 @@ def test_reference_callers_run_unmodified_against_the_product_cube_env():
     unmodified (make_golden.py's three harness shims) and driven with the product's CubeEnv class -- here its host logic over the
     oracle backend, tests/fake_backend.HostLogicCubeEnv -- and every observable (simulations used, action lists, node statistics,
     every env.step validation issues, solve steps, the replay deque, prioritised indices, __getitem__ dtypes, DataLoader order,
-    get_target_value) equals what the reference computed with its OWN env (G5, G8, G9, G11, G12).  27 checks; runs in a child
+    get_target_value) equals what the reference computed with its OWN env (G5, G8, G9, G11, G12; 2x2x2: G13).  33 checks; runs in a child
     process because the shims rebind `gym`, numpy.int and put the reference's `utils` / `test` / `model` modules on sys.path.
     The reference never travels: skipped where /root/reference is absent (the GPU box)."""
     import json
@@ -614,7 +614,7 @@ def test_reference_callers_run_unmodified_against_the_product_cube_env():
                          capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
-    assert d["failed"] == [] and len(d["checks"]) == 27 and all(d["checks"].values())
+    assert d["failed"] == [] and len(d["checks"]) == 33 and all(d["checks"].values())
     assert d["env_class"] == "rubiks_cube_solver_amd.cube_env" and d["reference_modules"] == ["mcts", "model", "test", "train", "utils"]
 
 
@@ -694,3 +694,55 @@ def test_a_stale_library_is_refused_and_rebuilt_by_id_not_by_mtime(tmp_path):
     plain = str(tmp_path / "no_id.so")
     open(plain, "wb").write(b"\x7fELF" + b"\0" * 64)
     assert _build.embedded_id(plain) is None and _build.embedded_id(str(tmp_path / "missing.so")) is None
+
+
+def test_cube_env_222_host_logic_against_the_references_own_222_branches(golden):
+    """Fixture G13 = the reference's OWN CubeEnv run with cube_size = 2 (stand-in py222).  The product's CubeEnv host logic (oracle backend)
+    against it: reset(seed, k) incl. the untouched global generator, step's 4-tuple and float64 [7, 21] one-hot (row = cubelet, column =
+    position * 3 + orientation: cube_env.py:143-147), state_to_sim_state (cube_env.py:154-175), get_random_samples records and the state
+    the env is left in (cube_env.py:177-194), get_target_value (cube_env.py:196-252) -- float-EQUAL: the host path calls the model as the
+    reference does."""
+    g = golden("env222_via_reference")
+    env = _env(2)
+    assert (env.sim_cube == g["solved_stickers"]).all() and (np.argmax(env.cube, 1) == g["solved_cols"]).all() and str(env.cube.dtype) == str(g["state_dtype"])
+    np.random.seed(99)
+    before = np.random.get_state()[1].copy()
+    for i, sd in enumerate(g["reset_seeds"]):
+        for j, k in enumerate(g["reset_ks"]):
+            s = env.reset(seed=int(sd), scramble_count=int(k))
+            assert s.dtype == np.float64 and (np.argmax(s, 1) == g["reset_cols"][i, j]).all() and (s.sum(1) == 1).all()
+            assert (env.sim_cube == g["reset_stickers"][i, j]).all()
+    assert (np.random.get_state()[1] == before).all()
+    for w in range(0, 300, 7):
+        env.init_state()
+        for d in range(14):
+            s, r, dn, info = env.step(int(g["walk_actions"][w, d]))
+            assert (env.sim_cube == g["walk_stickers"][w, d]).all() and (np.argmax(s, 1) == g["walk_cols"][w, d]).all()
+            assert isinstance(r, float) and isinstance(dn, bool) and (r, dn) == (g["walk_reward"][w, d], bool(g["walk_done"][w, d])) and info == {}
+            if d % 5 == 0:
+                assert (env.state_to_sim_state(env.cube) == g["roundtrip_stickers"][w, d // 5]).all()
+    w_, b_ = torch.tensor(g["adi_w"]), torch.tensor(g["adi_b"])
+
+    class StubModel(torch.nn.Module):
+        def forward(self, x):
+            if x.dim() == 2:
+                x = x.unsqueeze(0)
+            return (x.reshape(x.shape[0], -1) @ w_ + b_).unsqueeze(-1), torch.zeros(x.shape[0], 6)
+
+    model, T = StubModel(), float(g["adi_temperature"])
+    n, depth = g["adi_actions"].shape
+    buf = []
+    np.random.seed(int(g["adi_seed"]))
+    env.get_random_samples(buf, model, depth, n, T)
+    assert len(buf) == n * depth and (env.sim_cube == g["adi_final_stickers"]).all()
+    assert buf[0]["state"].dtype == np.float64 and buf[0]["state"].shape == (7, 21) and type(buf[0]["target_policy"]) is int
+    assert (np.stack([np.argmax(x["state"], 1) for x in buf]).reshape(n, depth, 7) == g["adi_cols"]).all()
+    assert (np.array([x["target_value"] for x in buf]).reshape(n, depth) == g["adi_target_value"]).all()
+    assert (np.array([x["target_policy"] for x in buf]).reshape(n, depth) == g["adi_target_policy"]).all()
+    assert (np.array([x["scramble_count"] for x in buf]).reshape(n, depth) == g["adi_scramble_count"]).all()
+    assert (np.array([x["error"] for x in buf]).reshape(n, depth) == g["adi_error"]).all()
+    env.init_state()
+    for d in range(depth):
+        env.step(int(g["adi_actions"][3, d]))
+        tv, tp, er = env.get_target_value(model, d + 1, T)
+        assert (tv, tp, er) == (g["adi_target_value"][3, d], g["adi_target_policy"][3, d], g["adi_error"][3, d])

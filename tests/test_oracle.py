@@ -3,6 +3,7 @@ import hashlib
 
 import numpy as np
 import pytest
+import torch
 
 from oracle.oracle_np import OracleCubeEnv, tables_222
 
@@ -217,7 +218,8 @@ def test_222_convention_evidence_in_the_fixture(golden):
 
 def test_committed_fixtures_are_the_references_outputs():
     """One command proves that tests/golden/*.npz are what the REFERENCE computes: make_golden.py --check imports the reference
-    (unmodified, three harness shims), regenerates all 11 3x3x3 fixture files into a temporary directory and compares every array
+    (unmodified, three harness shims), regenerates all 11 3x3x3 fixture files and the 2x2x2 file G13 (the reference's own CubeEnv /
+    MCTS with cube_size = 2 over the stand-in py222) into a temporary directory and compares every array
     (dtype, shape, values) with the committed ones.  Drives cube_env.py:50-111,177-252, mcts.py:36-154, utils.py:203-270,
     model.py:31-91.  The reference never travels: skipped where /root/reference is absent (the GPU box)."""
     import os
@@ -229,4 +231,57 @@ def test_committed_fixtures_are_the_references_outputs():
     out = subprocess.run([sys.executable, "-B", os.path.join(root, "tests", "golden", "make_golden.py"), "--check"],
                          capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert out.stdout.count(": IDENTICAL") == 11 and "11 of 11 fixtures IDENTICAL" in out.stdout
+    assert out.stdout.count(": IDENTICAL") == 12 and "12 of 12 fixtures IDENTICAL" in out.stdout
+
+
+def _cols_222(code):
+    """2x2x2 compact code (per slot: piece * 3 + orientation) -> per cubelet ROW the column of its 1 (cube_env.py:143-147:
+    state[cubelet][position * 3 + orientation] = 1.0), the form fixture G13 stores."""
+    code = np.asarray(code).astype(np.int64)
+    cols = np.zeros(code.shape, np.uint8)
+    np.put_along_axis(cols, code // 3, (np.arange(7) * 3 + code % 3).astype(np.uint8), -1)
+    return cols
+
+
+def test_env222_fixture_is_what_the_oracle_computes(oracle, golden):
+    """G13 = the REFERENCE's own CubeEnv / get_random_samples run with cube_size = 2 (cube_env.py:38,86-94,143-147,165-170,215-217), the
+    six py222 names supplied by tests/golden/py222_standin.py.  The C oracle and the numpy one-cube env reproduce it: stickers, the
+    transposed one-hot, reward / done, reset(seed, k) on the legacy generator, the state_to_sim_state inversion, the ADI targets."""
+    from oracle.oracle_np import OracleCubeEnv
+    g = golden("env222_via_reference")
+    assert str(g["state_dtype"]) == "float64" and list(g["action_names"]) == ["U", "U'", "F", "F'", "R", "R'"]
+    assert (oracle.solved(2, 1)[0] == g["solved_stickers"]).all() and (_cols_222(oracle.encode(2, oracle.solved(2, 1))[0])[0] == g["solved_cols"]).all()
+    # 300 walks x 14 moves through the batched C oracle, every step
+    W, D = g["walk_actions"].shape
+    st = oracle.solved(2, W)
+    for d in range(D):
+        st, code, done, rew = oracle.step(2, st, g["walk_actions"][:, d])
+        assert (st == g["walk_stickers"][:, d]).all() and (_cols_222(code) == g["walk_cols"][:, d]).all()
+        assert (done == g["walk_done"][:, d]).all() and (rew == g["walk_reward"][:, d]).all()
+    assert g["walk_done"].sum() > 20                                                  # solved states do occur (U then U', ...)
+    # the numpy one-cube env: reset(seed, k), dense one-hot dtype / layout, a walk, the ADI samples with the stub model (float-equal)
+    env = OracleCubeEnv(None, 2)
+    for i, sd in enumerate(g["reset_seeds"]):
+        for j, k in enumerate(g["reset_ks"]):
+            s = env.reset(seed=int(sd), scramble_count=int(k))
+            assert s.dtype == np.float64 and s.shape == (7, 21) and (np.argmax(s, 1) == g["reset_cols"][i, j]).all() and (s.sum(1) == 1).all()
+            assert (env.sim_cube == g["reset_stickers"][i, j]).all()
+    w, b = torch.tensor(g["adi_w"]), torch.tensor(g["adi_b"])
+
+    def model(x):
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+        return (x.reshape(x.shape[0], -1) @ w + b).unsqueeze(-1), torch.zeros(x.shape[0], 6)
+    buf = []
+    np.random.seed(int(g["adi_seed"]))
+    env.get_random_samples(buf, model, g["adi_actions"].shape[1], g["adi_actions"].shape[0], float(g["adi_temperature"]))
+    n, depth = g["adi_actions"].shape
+    assert len(buf) == n * depth and (env.sim_cube == g["adi_final_stickers"]).all()
+    assert (np.stack([np.argmax(x["state"], 1) for x in buf]).reshape(n, depth, 7) == g["adi_cols"]).all()
+    assert (np.array([x["target_value"] for x in buf]).reshape(n, depth) == g["adi_target_value"]).all()
+    assert (np.array([x["target_policy"] for x in buf]).reshape(n, depth) == g["adi_target_policy"]).all()
+    assert (np.array([x["error"] for x in buf]).reshape(n, depth) == g["adi_error"]).all()
+    assert (g["adi_target_value"][:, 0] == 1.0).all() and (g["adi_target_value"] == 1.0).sum() == 77      # depth 1: the inverse move solves
+    # the batched C oracle's ADI walk replay agrees on states and solved children
+    out = oracle.adi(2, n, depth, actions_in=g["adi_actions"], want_children=False)
+    assert (_cols_222(out["parent_code"]) == g["adi_cols"]).all() and (out["child_solved"].any(-1) == (g["adi_target_value"] == 1.0)).all()

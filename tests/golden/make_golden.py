@@ -14,7 +14,7 @@ seeds, stub-model weights) and the outputs the reference computed for them.
     python -B tests/golden/make_golden.py mcts            # only the named groups (tables walks reset adi expand encode mcts rollout adi_deepcube replay mcts_guided)
     python -B tests/golden/make_golden.py --out DIR       # write somewhere else
     python -B tests/golden/make_golden.py --check         # regenerate into a temp dir, compare every array with the committed fixtures
-                                                          # (11 x IDENTICAL; exit status 1 otherwise) -- tests/test_oracle.py runs it
+                                                          # (12 x IDENTICAL; exit status 1 otherwise) -- tests/test_oracle.py runs it
 
 Fixtures written (all small, np.savez_compressed):
   tables_333.npz   G1  tables as data (perm table, piece defs, hash weights, LUTs)
